@@ -1,0 +1,139 @@
+/* rovit_hip.h -- C ABI of librovit_hip.so: the MI355X (gfx950) kernels behind the RoViT-KAN hot path.
+ *
+ * The reference (nishitbohra/RoViT-KAN-...) has no native / FFI layer: its hot path is the Python nn.Module
+ * surface of models/rovit_kan.py, models/backbone.py, models/kan.py and models/heads.py.  This header is the
+ * boundary a maintainer would bind from those files (via ctypes); every entry point cites
+ * the reference code it replaces.
+ *
+ * Conventions
+ *   - plain C types only; all pointers are DEVICE pointers unless stated, owned by the caller;
+ *   - "bf16" buffers are passed as void* (16-bit brain-float, row-major, 16-byte aligned, leading dimension in
+ *     elements); float buffers are fp32 row-major;
+ *   - every function only ENQUEUES work on `stream` (a hipStream_t); it never allocates, never synchronises;
+ *   - return value: ROVIT_OK (0) or a negative error code; rovit_last_error_string() describes the failure
+ *     (thread-local).  There is no CPU fallback: without a GPU the launch fails and the code says so.
+ */
+#ifndef ROVIT_HIP_H
+#define ROVIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rovit_stream_t; /* hipStream_t */
+
+enum {
+  ROVIT_OK = 0,
+  ROVIT_ERR_SHAPE = -1,  /* unsupported / inconsistent shape */
+  ROVIT_ERR_ALIGN = -2,  /* pointer or leading dimension not aligned */
+  ROVIT_ERR_NULL = -3,   /* required pointer is NULL */
+  ROVIT_ERR_LAUNCH = -4  /* HIP reported a launch / memset error */
+};
+
+/* activation applied to a KAN layer's output (models/kan.py:141 ReLU between layers, :147 3*sigmoid) */
+enum { ROVIT_ACT_NONE = 0, ROVIT_ACT_RELU = 1, ROVIT_ACT_SIGMOID3 = 2 };
+/* flags of rovit_linear_fwd */
+enum { ROVIT_LIN_RELU = 1, ROVIT_LIN_CLAMP10 = 2 };
+/* epilogues of rovit_gemm_nt */
+enum { ROVIT_EPI_BF16 = 0, ROVIT_EPI_GELU = 1, ROVIT_EPI_RESID = 2, ROVIT_EPI_MUL = 3, ROVIT_EPI_PATCH = 4 };
+
+int rovit_version(void);
+const char* rovit_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * KAN head.  Replaces KANLayer.forward (models/kan.py:70-95) incl. BSplineBasis.compute_basis (:8-44) and the
+ * activation that follows the layer in KANSeverityModule.forward (:138-149); backward replaces autograd of same.
+ *   x (B,in)  spline_w (in,out,nb)  knots (n_knots,) with nb = n_knots-4 (degree 3)  lin_w (out,in)  lin_b (out)
+ *   out (B,out) = act(Linear(x) + sum_i sum_k basis_k(tanh x_i) spline_w[i,:,k])
+ * ------------------------------------------------------------------------------------------------------------ */
+/* BSplineBasis.compute_basis (models/kan.py:8-44) for degree 3: x_norm (n,) -> basis (n, n_knots-4) */
+int rovit_kan_basis(const float* x_norm, const float* knots, float* basis, int n, int n_knots, rovit_stream_t stream);
+int rovit_kan_layer_fwd(const float* x, const float* spline_w, const float* knots, const float* lin_w, const float* lin_b,
+                        float* out, int batch, int in_f, int out_f, int n_knots, int act, rovit_stream_t stream);
+/* out = the forward's post-activation output; dx may be NULL; d_spline_w/d_lin_w/d_lin_b NULL together */
+int rovit_kan_layer_bwd(const float* x, const float* spline_w, const float* knots, const float* lin_w, const float* out,
+                        const float* grad_out, float* dx, float* d_spline_w, float* d_lin_w, float* d_lin_b, int batch,
+                        int in_f, int out_f, int n_knots, int act, int accumulate_dx, rovit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * MLP heads.  rovit_linear_* are the building block (nn.Linear [+ReLU] [*dropout mask] [clamp +-10]);
+ * rovit_heads_* run ClassificationHead / OrdinalHead / UncertaintyHead.forward (models/heads.py:17-22, 38-43,
+ * 91-102) with the curriculum gate of RoViTKAN.forward (models/rovit_kan.py:93-116).
+ * params[14] / grads[14] order: cls.fc1.{w,b} cls.fc2.{w,b} ord.fc1.{w,b} ord.fc2.{w,b} unc.fc1.{w,b}
+ * unc.fc_mu.{w,b} unc.fc_logvar.{w,b}.  masks: HOST array of 3 device pointers (B,hid) holding the scaled
+ * dropout keep-mask, or NULL / NULL entries in eval mode.  hidden: (3,B,hid) workspace kept for backward.
+ * ------------------------------------------------------------------------------------------------------------ */
+int rovit_linear_fwd(const float* x, const float* w, const float* bias, const float* mask, float* y, int batch, int in_f,
+                     int out_f, int flags, rovit_stream_t stream);
+int rovit_linear_bwd(const float* x, const float* w, const float* grad_y, const float* y_clamped, const float* dx_mul,
+                     const float* dx_pos, float* dx, float* dw, float* db, int batch, int in_f, int out_f, int accumulate_dx,
+                     rovit_stream_t stream);
+int rovit_heads_fwd(const float* features, const float* const* params, const float* const* masks, float* hidden,
+                    float* cls_logits, float* ordinal_logits, float* mu, float* log_var, int batch, int embed, int hid,
+                    int num_classes, int stage, rovit_stream_t stream);
+int rovit_heads_bwd(const float* features, const float* const* params, const float* const* masks, const float* hidden,
+                    const float* log_var, const float* g_cls, const float* g_ord, const float* g_mu, const float* g_lv,
+                    float* d_features, float* const* grads, float* scratch, int batch, int embed, int hid, int num_classes,
+                    int accumulate_dfeat, rovit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * DeiT-Tiny backbone (models/backbone.py:23-25 -> timm VisionTransformer.forward).
+ * params / grads: HOST arrays of rovit_vit_num_params(depth) device pointers (fp32, timm layouts):
+ *   [0] cls_token (192) [1] pos_embed (197,192) [2] patch_embed.proj.weight (192,768) [3] .bias [4] norm.weight
+ *   [5] norm.bias, then per block b at 6+12b: norm1.{w,b} attn.qkv.{w,b} attn.proj.{w,b} norm2.{w,b} mlp.fc1.{w,b}
+ *   mlp.fc2.{w,b}.
+ * prep: rovit_vit_prep_bytes(depth) bytes, filled by rovit_vit_prepare (re-run after every parameter update).
+ * workspace: rovit_vit_workspace_bytes(batch, depth, training) bytes; in training mode it carries the saved
+ * activations from rovit_vit_forward to rovit_vit_backward.
+ * ------------------------------------------------------------------------------------------------------------ */
+int rovit_vit_num_params(int depth);
+size_t rovit_vit_prep_bytes(int depth);
+size_t rovit_vit_workspace_bytes(int batch, int depth, int training);
+int rovit_vit_prepare(const float* const* params, void* prep, int depth, rovit_stream_t stream);
+int rovit_vit_forward(const float* images, const float* const* params, const void* prep, void* workspace, float* features,
+                      int batch, int depth, int training, rovit_stream_t stream);
+int rovit_vit_backward(const float* d_features, const float* const* params, const void* prep, void* workspace,
+                       float* const* grads, int batch, int depth, int first_block, int last_block, rovit_stream_t stream);
+
+/* ---- the individual backbone kernels (used by rovit_vit_* and exposed for unit tests / profiling) ---------- */
+/* C = A(M,K) W(N,K)^T + bias with a fused epilogue:
+ *   BF16  out bf16 (M,N)                      GELU  out = gelu(c), out2 = gelu'(c)  (both bf16, ld = ldo)
+ *   RESID xres fp32 (M,N) += c                MUL   out = c * mul (bf16)
+ *   PATCH row m=(b,p) of M=B*(tokens-1) -> xres[b*tokens+1+p] = c + pos[1+p]                                 */
+int rovit_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, int epi, void* out,
+                  int ldo, void* out2, float* xres, int ldx, const void* mul, int ldm, const float* pos, int tokens,
+                  rovit_stream_t stream);
+int rovit_set_gemm_tile(int tile); /* tuning knob: 0 = 128x192 tiles where N allows, 1 = 128x96 */
+/* G(N,K) = dY(M,N)^T A(M,K) and colsum(dY), split over M into `splits` fp32 slabs inside ws */
+int rovit_wgrad_splits(int M, int N, int K);
+size_t rovit_wgrad_workspace_bytes(int N, int K, int splits);
+int rovit_wgrad(const void* dY, int ldy, const void* A, int lda, int M, int N, int K, int splits, int patch_tokens, float* ws,
+                rovit_stream_t stream);
+int rovit_wgrad_reduce(const float* ws, int splits, int N, int K, const float* gamma, const float* beta, const float* W,
+                       float* dW, float* db, float* dgamma, float* dbeta, float* g_scratch, rovit_stream_t stream);
+/* softmax(q k^T * scale) v per (image, head); qkv bf16 (B*T, 3*H*64) = [q|k|v]; out bf16 (B*T, H*64);
+ * lse2 (B,H,T) = log2 sum exp(scale q.k) */
+int rovit_attention_fwd(const void* qkv, void* out, float* lse2, int batch, int tokens, int heads, int head_dim, float scale,
+                        rovit_stream_t stream);
+int rovit_attention_bwd(const void* qkv, const void* out, const float* lse2, const void* dout, void* dqkv, int batch, int tokens,
+                        int heads, int head_dim, float scale, rovit_stream_t stream);
+int rovit_layernorm_fwd(const float* x, void* xhat, float* rstd, int rows, int dim, float eps, rovit_stream_t stream);
+int rovit_layernorm_bwd(const void* dxhat, const void* xhat, const float* rstd, float* dX, void* dXb, int rows, int dim,
+                        rovit_stream_t stream);
+int rovit_im2col(const float* x, void* col, int batch, rovit_stream_t stream);
+int rovit_cls_rows(const float* cls, const float* pos, float* X, int batch, int tokens, rovit_stream_t stream);
+int rovit_cls_norm_fwd(const float* X, const float* gamma, const float* beta, float* feat, float* xhat, float* rstd, int batch,
+                       int tokens, float eps, rovit_stream_t stream);
+int rovit_cls_norm_bwd(const float* dfeat, const float* xhat, const float* rstd, const float* gamma, float* dX, void* dXb,
+                       float* dgamma, float* dbeta, int batch, int tokens, rovit_stream_t stream);
+int rovit_pos_grad(const float* dX, float* dpos, float* dcls, int batch, int tokens, rovit_stream_t stream);
+int rovit_prep_weight(const float* W, const float* bias, const float* gamma, const float* beta, void* Wf, void* WfT,
+                      float* bias_f, int N, int K, rovit_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROVIT_HIP_H */

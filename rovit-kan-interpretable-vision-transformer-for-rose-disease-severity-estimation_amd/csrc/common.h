@@ -1,0 +1,95 @@
+// Shared device/host helpers for the gfx950 kernels of the RoViT-KAN hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/rovit_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define ROVIT_WAVE 64
+
+// ---- error plumbing ------------------------------------------------------------------
+void rovit_set_error(const char* fmt, ...);
+
+#define ROVIT_CHECK_ARG(cond, code, ...)        \
+  do {                                          \
+    if (!(cond)) {                              \
+      rovit_set_error(__VA_ARGS__);             \
+      return (code);                            \
+    }                                           \
+  } while (0)
+
+#define ROVIT_CHECK_LAUNCH(name)                                                  \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      rovit_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+      return ROVIT_ERR_LAUNCH;                                                    \
+    }                                                                             \
+  } while (0)
+
+static inline bool rovit_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- device helpers ------------------------------------------------------------------
+#ifdef __HIPCC__
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  // D[row][col] += sum_k A[row][k] B[k][col];  lane l supplies A[row = l&15][k-slots of group l>>4]
+  // and B[k-slots][col = l&15]; holds D[row = 4*(l>>4)+r][col = l&15] in c[r].
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of row q, columns
+// 4p..4p+3 of a 4x16 block of 16-bit elements; lane i receives column i (row q in element q).
+__device__ __forceinline__ bf16x4 lds_read_tr(const bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+      (__attribute__((address_space(3))) bf16x4*)(p));
+}
+
+__device__ __forceinline__ bf16x8 cat4(bf16x4 lo, bf16x4 hi) {
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
+  bf16x8 r;
+  r[0] = (bf16)lo[0]; r[1] = (bf16)lo[1]; r[2] = (bf16)lo[2]; r[3] = (bf16)lo[3];
+  r[4] = (bf16)hi[0]; r[5] = (bf16)hi[1]; r[6] = (bf16)hi[2]; r[7] = (bf16)hi[3];
+  return r;
+}
+
+__device__ __forceinline__ bf16x4 pack4(f32x4 v) {
+  bf16x4 r;
+  r[0] = (bf16)v[0]; r[1] = (bf16)v[1]; r[2] = (bf16)v[2]; r[3] = (bf16)v[3];
+  return r;
+}
+
+// Workgroup ids b, b+8, b+16, ... are observed to share an XCD (round-robin dispatch); this bijection gives
+// XCD x the contiguous id range [start_x, start_x + count_x) so neighbouring tiles share one L2.
+// Speed only: nothing depends on the placement actually happening.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+__device__ __forceinline__ float wave_sum16(float v) {   // sum over the 16 lanes sharing l>>4
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+  return v;
+}
+__device__ __forceinline__ float wave_sum64(float v) {
+  v = wave_sum16(v); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+  return v;
+}
+// reduce over the 4 lane groups (lanes l, l^16, l^32, l^48)
+__device__ __forceinline__ float group4_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
+__device__ __forceinline__ float group4_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 32));
+  return v;
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,456 @@
+// bf16 MFMA GEMMs for the DeiT-Tiny token matrix (M = B*197 rows, K/N in {192, 576, 768}).
+//
+//   gemm_nt   C[M,N] = A[M,K] * W[N,K]^T  (+ fused epilogue)       forward linears and dgrads
+//   wgrad     G[N,K] = dY[M,N]^T * A[M,K], colsum(dY)               weight gradients (split over M, slabs)
+//
+// Reference arithmetic being restated: timm VisionTransformer's Linear layers (qkv/proj/fc1/fc2, patch-embed
+// conv as an im2col GEMM) reached through /root/reference/models/backbone.py:12-25, and their autograd
+// backward (training/trainer.py:119,136).
+//
+// MFMA: v_mfma_f32_16x16x32_bf16, fp32 accumulate.  The accumulator is computed TRANSPOSED (weights as the
+// MFMA "A" operand) so that each lane ends up with 4 consecutive output columns of one row: 8-byte bf16 /
+// 16-byte fp32 epilogue accesses.  Workgroup ids are remapped so that all column tiles of one row panel (and
+// all output tiles of one M-split in wgrad) run on the same XCD and share that XCD's L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int LDS_STRIDE = BK + 16;      // bf16 elements; 160-byte rows: conflict-free ds_read_b128 fragments
+
+enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_MUL = 3, EPI_PATCH = 4 };
+
+struct GemmArgs {
+  const bf16* A; int lda;
+  const bf16* W; int ldw;
+  int M, N, K;
+  const float* bias;
+  bf16* out; int ldo;
+  bf16* out2;
+  float* xres; int ldx;
+  const bf16* mul; int ldm;
+  const float* pos; int tokens;
+  int n_tiles;
+};
+
+__device__ __forceinline__ float gelu_cdf(float x) { return 0.5f * (1.f + erff(x * 0.70710678118654752f)); }
+
+template <int EPI>
+__device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, f32x4 v) {
+  if (g.bias) {
+    const float4 b = *(const float4*)(g.bias + n);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (EPI == EPI_BF16) {
+    *(bf16x4*)(g.out + (size_t)m * g.ldo + n) = pack4(v);
+  } else if (EPI == EPI_GELU) {
+    f32x4 a, d;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float x = v[r];
+      const float cdf = gelu_cdf(x);
+      a[r] = x * cdf;                                                      // exact-erf GELU (timm default)
+      d[r] = cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);        // d gelu / dx
+    }
+    *(bf16x4*)(g.out + (size_t)m * g.ldo + n) = pack4(a);
+    if (g.out2) *(bf16x4*)(g.out2 + (size_t)m * g.ldo + n) = pack4(d);
+  } else if (EPI == EPI_RESID) {
+    float4* p = (float4*)(g.xres + (size_t)m * g.ldx + n);
+    float4 x = *p;
+    x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
+    *p = x;
+  } else if (EPI == EPI_MUL) {
+    const bf16x4 q = *(const bf16x4*)(g.mul + (size_t)m * g.ldm + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= (float)q[r];
+    *(bf16x4*)(g.out + (size_t)m * g.ldo + n) = pack4(v);
+  } else if (EPI == EPI_PATCH) {
+    const int np = g.tokens - 1;
+    const int b = m / np, p = m - b * np;
+    const float4 pe = *(const float4*)(g.pos + (size_t)(p + 1) * g.N + n);
+    float4 x = make_float4(v[0] + pe.x, v[1] + pe.y, v[2] + pe.z, v[3] + pe.w);
+    *(float4*)(g.xres + ((size_t)b * g.tokens + 1 + p) * g.ldx + n) = x;
+  }
+}
+
+// BM x BN output tile, WM x WN waves, K looped in steps of 64 through a double-buffered LDS ring filled by
+// register staging (global_load_dwordx4 -> ds_write_b128 after the compute of the previous tile).
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmArgs g) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN;       // wave tile
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  constexpr int CPR = BK / 8;                       // 16-byte chunks per tile row
+  constexpr int CA = BM * CPR / NT, CB = BN * CPR / NT;
+  static_assert(BM * CPR % NT == 0 && BN * CPR % NT == 0, "tile/threads mismatch");
+  extern __shared__ __attribute__((aligned(16))) bf16 lds[];
+  bf16* As = lds;                                   // [2][BM][LDS_STRIDE]
+  bf16* Bs = lds + 2 * BM * LDS_STRIDE;             // [2][BN][LDS_STRIDE]
+
+  // XCD-aware tile id: ids b, b+8, ... share an XCD; give one XCD all column tiles of a row panel.
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = bid / g.n_tiles, nt = bid - mt * g.n_tiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  if (m0 >= g.M) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  const bf16* a_src[CA];
+  const bf16* b_src[CB];
+  int a_dst[CA], b_dst[CB];
+#pragma unroll
+  for (int i = 0; i < CA; ++i) {
+    const int c = tid + i * NT, row = c / CPR, kc = c - row * CPR;
+    int gr = m0 + row; gr = gr < g.M ? gr : g.M - 1;
+    a_src[i] = g.A + (size_t)gr * g.lda + kc * 8;
+    a_dst[i] = row * LDS_STRIDE + kc * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < CB; ++i) {
+    const int c = tid + i * NT, row = c / CPR, kc = c - row * CPR;
+    b_src[i] = g.W + (size_t)(n0 + row) * g.ldw + kc * 8;
+    b_dst[i] = row * LDS_STRIDE + kc * 8;
+  }
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 ra[CA], rb[CB];
+  const int nk = g.K / BK;
+#pragma unroll
+  for (int i = 0; i < CA; ++i) ra[i] = *(const bf16x8*)(a_src[i]);
+#pragma unroll
+  for (int i = 0; i < CB; ++i) rb[i] = *(const bf16x8*)(b_src[i]);
+#pragma unroll
+  for (int i = 0; i < CA; ++i) *(bf16x8*)(As + a_dst[i]) = ra[i];
+#pragma unroll
+  for (int i = 0; i < CB; ++i) *(bf16x8*)(Bs + b_dst[i]) = rb[i];
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < CA; ++i) ra[i] = *(const bf16x8*)(a_src[i] + (kt + 1) * BK);
+#pragma unroll
+      for (int i = 0; i < CB; ++i) rb[i] = *(const bf16x8*)(b_src[i] + (kt + 1) * BK);
+    }
+    const bf16* Ac = As + cur * BM * LDS_STRIDE + (wm * WTM + l15) * LDS_STRIDE + lg * 8;
+    const bf16* Bc = Bs + cur * BN * LDS_STRIDE + (wn * WTN + l15) * LDS_STRIDE + lg * 8;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(Ac + i * 16 * LDS_STRIDE + ks * 32);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[j] = *(const bf16x8*)(Bc + j * 16 * LDS_STRIDE + ks * 32);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);   // D[n][m]
+    }
+    if (kt + 1 < nk) {
+      bf16* An = As + (cur ^ 1) * BM * LDS_STRIDE;
+      bf16* Bn = Bs + (cur ^ 1) * BN * LDS_STRIDE;
+#pragma unroll
+      for (int i = 0; i < CA; ++i) *(bf16x8*)(An + a_dst[i]) = ra[i];
+#pragma unroll
+      for (int i = 0; i < CB; ++i) *(bf16x8*)(Bn + b_dst[i]) = rb[i];
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + l15;
+    if (m < g.M) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) epilogue4<EPI>(g, m, n0 + wn * WTN + j * 16 + lg * 4, acc[i][j]);
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_nt(const GemmArgs& g0, int epi, hipStream_t st) {
+  GemmArgs g = g0;
+  g.n_tiles = g.N / BN;
+  const int m_tiles = (g.M + BM - 1) / BM;
+  const int nwg = m_tiles * g.n_tiles;
+  const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(bf16);
+  dim3 grid(nwg), block(WM * WN * 64);
+#define LAUNCH(E)                                                                                         \
+  case E: {                                                                                               \
+    static bool attr_set = false;                                                                         \
+    if (!attr_set) {                                                                                      \
+      (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, WM, WN, E>,                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+      attr_set = true;                                                                                    \
+    }                                                                                                     \
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, E>), grid, block, lds, st, g);                     \
+    break;                                                                                                \
+  }
+  switch (epi) {
+    LAUNCH(EPI_BF16) LAUNCH(EPI_GELU) LAUNCH(EPI_RESID) LAUNCH(EPI_MUL) LAUNCH(EPI_PATCH)
+    default: rovit_set_error("gemm_nt: unknown epilogue %d", epi); return ROVIT_ERR_SHAPE;
+  }
+#undef LAUNCH
+  ROVIT_CHECK_LAUNCH("gemm_nt_kernel");
+  return ROVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// wgrad: G[n][k] = sum_m dY[m][n] A[m][k] over one M-split, written to slab[split][n][k] (fp32);
+// colsum[split][n] = sum_m dY[m][n] comes out of one extra MFMA against a tile of ones.
+// Both operands are m-major, so their MFMA fragments are gathered with ds_read_b64_tr_b16 from row-major
+// LDS tiles.  Contraction slot (group g, element j) of a 32-row step holds row 16*(j>>2) + 4*g + (j&3):
+// the two 16-lane groups of a half-wave then read 8 consecutive LDS rows (conflict-free at a 224-byte stride).
+// ------------------------------------------------------------------------------------------------------
+constexpr int WG_T = 96;                      // output tile edge (n and k)
+constexpr int WG_MSTEP = 64;
+constexpr int WG_STRIDE = WG_T + 16;          // 224-byte rows
+
+struct WgradArgs {
+  const bf16* dY; int ldy;
+  const bf16* A; int lda;
+  int M, N, K;
+  int splits, rows_per_split;
+  float* slab;          // [splits][N][K]
+  float* colsum;        // [splits][N]
+  int patch_tokens;     // >0: dY row of m is m + m/(T-1) + 1 (skip each image's cls row)
+  int k_tiles, n_tiles;
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
+  constexpr int CPR = WG_T / 8;                         // 12 chunks per row
+  constexpr int CH = WG_MSTEP * CPR / 256;              // 3 chunks per thread per operand
+  __shared__ __attribute__((aligned(16))) bf16 lds[2 * 2 * WG_MSTEP * WG_STRIDE];
+  bf16* Ys = lds;                                       // [2][MSTEP][STRIDE]
+  bf16* As = lds + 2 * WG_MSTEP * WG_STRIDE;
+
+  const int tiles = g.k_tiles * g.n_tiles;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);            // all tiles of a split on one XCD
+  const int split = bid / tiles, tile = bid - split * tiles;
+  if (split >= g.splits) return;
+  const int ntile = tile / g.k_tiles, ktile = tile - ntile * g.k_tiles;
+  const int n0 = ntile * WG_T, k0 = ktile * WG_T;
+  const int m_begin = split * g.rows_per_split;
+  const int m_end = min(g.M, m_begin + g.rows_per_split);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave >> 1, wn = wave & 1;              // wave tile: k rows [48*wk, +48), n cols [48*wn, +48)
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  int c_row[CH], c_col[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = tid + i * 256;
+    c_row[i] = c / CPR; c_col[i] = (c - c_row[i] * CPR) * 8;
+  }
+  auto load = [&](int mbase, bf16x8* ry, bf16x8* ra) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int m = mbase + c_row[i];
+      bf16x8 z;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) z[q] = (bf16)0.f;
+      ry[i] = z; ra[i] = z;
+      if (m < m_end) {
+        const int yr = g.patch_tokens > 0 ? m + m / (g.patch_tokens - 1) + 1 : m;
+        ry[i] = *(const bf16x8*)(g.dY + (size_t)yr * g.ldy + n0 + c_col[i]);
+        ra[i] = *(const bf16x8*)(g.A + (size_t)m * g.lda + k0 + c_col[i]);
+      }
+    }
+  };
+  auto store = [&](int buf, const bf16x8* ry, const bf16x8* ra) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      *(bf16x8*)(Ys + (buf * WG_MSTEP + c_row[i]) * WG_STRIDE + c_col[i]) = ry[i];
+      *(bf16x8*)(As + (buf * WG_MSTEP + c_row[i]) * WG_STRIDE + c_col[i]) = ra[i];
+    }
+  };
+
+  f32x4 acc[3][3], accb[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8 ones;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) ones[q] = (bf16)1.0f;
+
+  bf16x8 ry[CH], ra[CH];
+  load(m_begin, ry, ra);
+  store(0, ry, ra);
+  __syncthreads();
+  const int nsteps = (m_end - m_begin + WG_MSTEP - 1) / WG_MSTEP;
+  // transposed-read lane address inside a [rows][WG_STRIDE] tile: row 4*lg + (l15>>2), col 4*(l15&3)
+  const int tr_off = (4 * lg + (l15 >> 2)) * WG_STRIDE + 4 * (l15 & 3);
+  for (int s = 0; s < nsteps; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < nsteps) load(m_begin + (s + 1) * WG_MSTEP, ry, ra);
+    const bf16* Yc = Ys + cur * WG_MSTEP * WG_STRIDE + tr_off + wn * 48;
+    const bf16* Ac = As + cur * WG_MSTEP * WG_STRIDE + tr_off + wk * 48;
+#pragma unroll
+    for (int ms = 0; ms < WG_MSTEP / 32; ++ms) {
+      bf16x8 fa[3], fy[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const bf16* p = Ac + ms * 32 * WG_STRIDE + i * 16;
+        fa[i] = cat4(lds_read_tr(p), lds_read_tr(p + 16 * WG_STRIDE));
+        const bf16* q = Yc + ms * 32 * WG_STRIDE + i * 16;
+        fy[i] = cat4(lds_read_tr(q), lds_read_tr(q + 16 * WG_STRIDE));
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(fa[i], fy[j], acc[i][j]);      // D[k][n]
+      if (ktile == 0 && wk == 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) accb[j] = mfma16(ones, fy[j], accb[j]);
+      }
+    }
+    if (s + 1 < nsteps) store(cur ^ 1, ry, ra);
+    __syncthreads();
+  }
+  float* slab = g.slab + (size_t)split * g.N * g.K;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int n = n0 + wn * 48 + j * 16 + l15;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int k = k0 + wk * 48 + i * 16 + lg * 4;
+      *(float4*)(slab + (size_t)n * g.K + k) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+    if (ktile == 0 && wk == 0 && lg == 0) g.colsum[(size_t)split * g.N + n] = accb[j][0];
+  }
+}
+
+// sum the slabs of one wgrad; optionally un-fold the LayerNorm affine that was folded into the weight:
+//   W_f = W * gamma (per k), b_f = b + W beta   =>   dW = gamma * G + beta (x) db,  dgamma = sum_n W G,
+//   dbeta = sum_n W db.  dgamma/dbeta are finished by wgrad_affine_kernel.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ colsum,
+                                                           int splits, int N, int K, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ dW,
+                                                           float* __restrict__ db, float* __restrict__ Gout) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int total = N * K;
+  if (e < total) {
+    float s = 0.f;
+    for (int i = 0; i < splits; ++i) s += slab[(size_t)i * total + e];
+    if (gamma) {
+      const int n = e / K, k = e - n * K;
+      float cb = 0.f;
+      for (int i = 0; i < splits; ++i) cb += colsum[(size_t)i * N + n];
+      Gout[e] = s;
+      dW[e] = gamma[k] * s + beta[k] * cb;
+    } else {
+      dW[e] = s;
+    }
+  }
+  if (e < N) {
+    float cb = 0.f;
+    for (int i = 0; i < splits; ++i) cb += colsum[(size_t)i * N + e];
+    db[e] = cb;
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_affine_kernel(const float* __restrict__ G, const float* __restrict__ W,
+                                                           const float* __restrict__ db, int N, int K,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  float sg = 0.f, sb = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float w = W[(size_t)n * K + k];
+    sg = fmaf(w, G[(size_t)n * K + k], sg);
+    sb = fmaf(w, db[n], sb);
+  }
+  dgamma[k] = sg; dbeta[k] = sb;
+}
+
+}  // namespace
+
+static int g_gemm_tile = 0;      // 0: 128x192 tiles, 1: 128x96 tiles
+extern "C" int rovit_set_gemm_tile(int t) { g_gemm_tile = t; return ROVIT_OK; }
+
+extern "C" int rovit_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, int epi,
+                             void* out, int ldo, void* out2, float* xres, int ldx, const void* mul, int ldm,
+                             const float* pos, int tokens, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(A && W, ROVIT_ERR_NULL, "gemm_nt: null operand");
+  ROVIT_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % BK == 0 && N % 96 == 0, ROVIT_ERR_SHAPE,
+                  "gemm_nt: unsupported shape M=%d N=%d K=%d (K %% 64, N %% 96)", M, N, K);
+  ROVIT_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && rovit_aligned16(A) && rovit_aligned16(W), ROVIT_ERR_ALIGN,
+                  "gemm_nt: operands must be 16-byte aligned with ld %% 8 == 0");
+  GemmArgs g{};
+  g.A = (const bf16*)A; g.lda = lda; g.W = (const bf16*)W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias;
+  g.out = (bf16*)out; g.ldo = ldo; g.out2 = (bf16*)out2; g.xres = xres; g.ldx = ldx; g.mul = (const bf16*)mul; g.ldm = ldm;
+  g.pos = pos; g.tokens = tokens;
+  switch (epi) {
+    case EPI_BF16: case EPI_GELU: ROVIT_CHECK_ARG(out && ldo % 4 == 0, ROVIT_ERR_NULL, "gemm_nt: bf16 output missing"); break;
+    case EPI_RESID: ROVIT_CHECK_ARG(xres && ldx % 4 == 0, ROVIT_ERR_NULL, "gemm_nt: residual stream missing"); break;
+    case EPI_MUL: ROVIT_CHECK_ARG(out && mul, ROVIT_ERR_NULL, "gemm_nt: multiplier missing"); break;
+    case EPI_PATCH: ROVIT_CHECK_ARG(xres && pos && tokens > 1 && M % (tokens - 1) == 0, ROVIT_ERR_SHAPE, "gemm_nt: bad patch epilogue"); break;
+    default: ROVIT_CHECK_ARG(false, ROVIT_ERR_SHAPE, "gemm_nt: unknown epilogue %d", epi);
+  }
+  if (g_gemm_tile == 0 && N % 192 == 0) return launch_nt<128, 192, 2, 2>(g, epi, (hipStream_t)stream);
+  return launch_nt<128, 96, 2, 2>(g, epi, (hipStream_t)stream);
+}
+
+extern "C" size_t rovit_wgrad_workspace_bytes(int N, int K, int splits) {
+  return ((size_t)splits * N * K + (size_t)splits * N) * sizeof(float);
+}
+
+extern "C" int rovit_wgrad_splits(int M, int N, int K) {
+  const int tiles = (N / WG_T) * (K / WG_T);
+  int s = (512 + tiles - 1) / tiles;               // ~2 workgroups per CU
+  s = (s + 7) / 8 * 8;
+  const int max_s = (M + WG_MSTEP - 1) / WG_MSTEP;
+  if (s > max_s) s = max_s;
+  return s < 1 ? 1 : s;
+}
+
+// slab/colsum live in `ws` (rovit_wgrad_workspace_bytes); results are produced by rovit_wgrad_reduce.
+extern "C" int rovit_wgrad(const void* dY, int ldy, const void* A, int lda, int M, int N, int K, int splits, int patch_tokens,
+                           float* ws, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(dY && A && ws, ROVIT_ERR_NULL, "wgrad: null pointer");
+  ROVIT_CHECK_ARG(M > 0 && N % WG_T == 0 && K % WG_T == 0 && splits > 0, ROVIT_ERR_SHAPE, "wgrad: unsupported shape N=%d K=%d", N, K);
+  ROVIT_CHECK_ARG(ldy % 8 == 0 && lda % 8 == 0 && rovit_aligned16(dY) && rovit_aligned16(A), ROVIT_ERR_ALIGN, "wgrad: alignment");
+  WgradArgs g{};
+  g.dY = (const bf16*)dY; g.ldy = ldy; g.A = (const bf16*)A; g.lda = lda; g.M = M; g.N = N; g.K = K;
+  g.splits = splits;
+  g.rows_per_split = ((M + splits - 1) / splits + WG_MSTEP - 1) / WG_MSTEP * WG_MSTEP;
+  g.slab = ws; g.colsum = ws + (size_t)splits * N * K;
+  g.patch_tokens = patch_tokens;
+  g.k_tiles = K / WG_T; g.n_tiles = N / WG_T;
+  // a split whose first row is past M still writes zeros, so the reduce can sum every slab
+  const int nwg = splits * g.k_tiles * g.n_tiles;
+  hipLaunchKernelGGL(wgrad_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, g);
+  ROVIT_CHECK_LAUNCH("wgrad_kernel");
+  return ROVIT_OK;
+}
+
+extern "C" int rovit_wgrad_reduce(const float* ws, int splits, int N, int K, const float* gamma, const float* beta,
+                                  const float* W, float* dW, float* db, float* dgamma, float* dbeta, float* g_scratch,
+                                  rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(ws && dW && db, ROVIT_ERR_NULL, "wgrad_reduce: null pointer");
+  const float* slab = ws;
+  const float* colsum = ws + (size_t)splits * N * K;
+  if (gamma) ROVIT_CHECK_ARG(beta && W && dgamma && dbeta && g_scratch, ROVIT_ERR_NULL, "wgrad_reduce: affine un-fold needs beta/W/outputs");
+  const int total = N * K;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, slab, colsum, splits,
+                     N, K, gamma, beta, dW, db, g_scratch);
+  ROVIT_CHECK_LAUNCH("wgrad_reduce_kernel");
+  if (gamma) {
+    hipLaunchKernelGGL(wgrad_affine_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_scratch, W, db, N, K,
+                       dgamma, dbeta);
+    ROVIT_CHECK_LAUNCH("wgrad_affine_kernel");
+  }
+  return ROVIT_OK;
+}

@@ -1,0 +1,460 @@
+// KAN B-spline head and the three MLP heads: fp32 wavefront-level kernels (no MFMA).
+//
+// Reference semantics:
+//   KANLayer.forward            /root/reference/models/kan.py:70-95   (tanh -> truncated cubic basis ->
+//                                                                       spline contraction + Linear(x))
+//   BSplineBasis.compute_basis  models/kan.py:8-44                     (closed form: SURVEY.md 8(a) addendum)
+//   KANSeverityModule.forward   models/kan.py:138-149                  (ReLU between layers, 3*sigmoid at the end)
+//   Classification/Ordinal/UncertaintyHead.forward  models/heads.py:17-22, 38-43, 91-102
+//
+// The (B, in, num_basis) basis tensor the reference materialises (kan.py:20) never exists here: per
+// (sample, input feature) the kernel keeps the knot interval index and the 4 non-zero cubic values in LDS.
+#include "common.h"
+
+namespace {
+
+constexpr int KAN_MAX_KNOTS = 64;
+
+struct Basis4 {
+  int j;        // knot interval, -1 when every basis value is zero (beyond the truncation / saturated)
+  float v[4];   // value of basis j-m, m = 0..3
+};
+
+// knots: LDS or global pointer to nk fp32 knots (uniform by construction, but the STORED values are used
+// for the interval search and for h, as the reference does: kan.py:24,33-38).
+template <bool DERIV>
+__device__ __forceinline__ Basis4 kan_basis(float xn, const float* knots, int nk, float inv_h0, float* dv) {
+  Basis4 r;
+  const int nb = nk - 4;
+  const float t0 = knots[0], tl = knots[nk - 1];
+  float xc = fminf(fmaxf(xn, t0), tl);                         // kan.py:16
+  int j = (int)floorf((xc - t0) * inv_h0);
+  j = j < 0 ? 0 : (j > nk - 1 ? nk - 1 : j);
+  while (j > 0 && xc < knots[j]) --j;                          // exact search on the stored knots
+  while (j < nk - 1 && xc >= knots[j + 1]) ++j;
+  if (j >= nb) {                                               // truncation: SURVEY.md 0.2
+    r.j = -1; r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.f;
+    if (DERIV) dv[0] = dv[1] = dv[2] = dv[3] = 0.f;
+    return r;
+  }
+  const float tj = knots[j];
+  const float h = knots[j + 1] - tj;
+  const float u = (xc - tj) / h;
+  const float u2 = u * u, u3 = u2 * u, om = 1.f - u;
+  r.j = j;
+  r.v[0] = u3 * (1.f / 6.f);
+  r.v[1] = (-3.f * u3 + 3.f * u2 + 3.f * u + 1.f) * (1.f / 6.f);
+  r.v[2] = (3.f * u3 - 6.f * u2 + 4.f) * (1.f / 6.f);
+  r.v[3] = om * om * om * (1.f / 6.f);
+  if (DERIV) {
+    const float ih = 1.f / h;
+    dv[0] = 0.5f * u2 * ih;
+    dv[1] = (-9.f * u2 + 6.f * u + 3.f) * (1.f / 6.f) * ih;
+    dv[2] = (9.f * u2 - 12.f * u) * (1.f / 6.f) * ih;
+    dv[3] = -0.5f * om * om * ih;
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+    if (j - m < 0) { r.v[m] = 0.f; if (DERIV) dv[m] = 0.f; }   // left edge loses terms
+  return r;
+}
+
+__device__ __forceinline__ float act_apply(float z, int act) {
+  if (act == ROVIT_ACT_RELU) return fmaxf(z, 0.f);
+  if (act == ROVIT_ACT_SIGMOID3) return 3.f / (1.f + __expf(-z));
+  return z;
+}
+// d(act)/dz expressed through the post-activation value y
+__device__ __forceinline__ float act_grad(float g, float y, int act) {
+  if (act == ROVIT_ACT_RELU) return y > 0.f ? g : 0.f;
+  if (act == ROVIT_ACT_SIGMOID3) return g * y * (1.f - y * (1.f / 3.f));
+  return g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: one workgroup = TB samples.  Phase 1: per (sample, feature) tanh + grid lookup -> LDS.
+// Phase 2: thread = (sample, output): 4 FMAs against the W[i, o, j-3..j] slab + the linear term.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kan_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                      const float* __restrict__ knots, const float* __restrict__ lw,
+                                                      const float* __restrict__ lb, float* __restrict__ out, int B,
+                                                      int in_f, int out_f, int nk, int TB, int act) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_knots = smem;
+  float* s_x = s_knots + KAN_MAX_KNOTS;
+  float* s_v = s_x + TB * in_f;
+  int* s_j = (int*)(s_v + 4 * TB * in_f);
+  const int tid = threadIdx.x;
+  const int nb = nk - 4;
+  const int b0 = blockIdx.x * TB;
+  if (tid < nk) s_knots[tid] = knots[tid];
+  __syncthreads();
+  const float inv_h0 = 1.f / (s_knots[1] - s_knots[0]);
+  for (int e = tid; e < TB * in_f; e += 256) {
+    const int bl = e / in_f, i = e - bl * in_f, b = b0 + bl;
+    float xv = 0.f;
+    Basis4 bs; bs.j = -1; bs.v[0] = bs.v[1] = bs.v[2] = bs.v[3] = 0.f;
+    if (b < B) {
+      xv = x[(size_t)b * in_f + i];
+      bs = kan_basis<false>(tanhf(xv), s_knots, nk, inv_h0, nullptr);
+    }
+    s_x[e] = xv;
+    s_j[e] = bs.j;
+    *(float4*)(s_v + 4 * e) = make_float4(bs.v[0], bs.v[1], bs.v[2], bs.v[3]);
+  }
+  __syncthreads();
+  for (int e = tid; e < TB * out_f; e += 256) {
+    const int bl = e / out_f, o = e - bl * out_f, b = b0 + bl;
+    if (b >= B) continue;
+    float acc = lb[o];
+    const float* lwo = lw + (size_t)o * in_f;
+    for (int i = 0; i < in_f; ++i) {
+      const int q = bl * in_f + i;
+      acc = fmaf(s_x[q], lwo[i], acc);
+      const int j = s_j[q];
+      if (j >= 0) {
+        const float4 v = *(const float4*)(s_v + 4 * q);
+        const float* w = W + ((size_t)i * out_f + o) * nb;
+        acc = fmaf(v.x, w[j], acc);
+        if (j >= 1) acc = fmaf(v.y, w[j - 1], acc);
+        if (j >= 2) acc = fmaf(v.z, w[j - 2], acc);
+        if (j >= 3) acc = fmaf(v.w, w[j - 3], acc);
+      }
+    }
+    out[(size_t)b * out_f + o] = act_apply(acc, act);
+  }
+}
+
+// backward wrt the layer input: thread = (sample, feature)
+__global__ __launch_bounds__(256) void kan_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                         const float* __restrict__ knots, const float* __restrict__ lw,
+                                                         const float* __restrict__ y, const float* __restrict__ gy,
+                                                         float* __restrict__ dx, int B, int in_f, int out_f, int nk,
+                                                         int TB, int act, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_knots = smem;
+  float* s_g = s_knots + KAN_MAX_KNOTS;      // TB * out_f : dL/dz
+  const int tid = threadIdx.x;
+  const int nb = nk - 4;
+  const int b0 = blockIdx.x * TB;
+  if (tid < nk) s_knots[tid] = knots[tid];
+  for (int e = tid; e < TB * out_f; e += 256) {
+    const int bl = e / out_f, b = b0 + bl;
+    s_g[e] = b < B ? act_grad(gy[(size_t)b0 * out_f + e], y[(size_t)b0 * out_f + e], act) : 0.f;
+  }
+  __syncthreads();
+  const float inv_h0 = 1.f / (s_knots[1] - s_knots[0]);
+  for (int e = tid; e < TB * in_f; e += 256) {
+    const int bl = e / in_f, i = e - bl * in_f, b = b0 + bl;
+    if (b >= B) continue;
+    const float xv = x[(size_t)b * in_f + i];
+    const float xn = tanhf(xv);
+    float dv[4];
+    const Basis4 bs = kan_basis<true>(xn, s_knots, nk, inv_h0, dv);
+    const float* g = s_g + bl * out_f;
+    float lin = 0.f, spl = 0.f;
+    for (int o = 0; o < out_f; ++o) {
+      const float go = g[o];
+      lin = fmaf(go, lw[(size_t)o * in_f + i], lin);
+      if (bs.j >= 0) {
+        const float* w = W + ((size_t)i * out_f + o) * nb;
+        float s = dv[0] * w[bs.j];
+        if (bs.j >= 1) s = fmaf(dv[1], w[bs.j - 1], s);
+        if (bs.j >= 2) s = fmaf(dv[2], w[bs.j - 2], s);
+        if (bs.j >= 3) s = fmaf(dv[3], w[bs.j - 3], s);
+        spl = fmaf(go, s, spl);
+      }
+    }
+    const float r = fmaf(spl, 1.f - xn * xn, lin);       // d tanh; clamp is the identity on (-1, 1)
+    float* p = dx + (size_t)b * in_f + i;
+    *p = accumulate ? *p + r : r;
+  }
+}
+
+// backward wrt the parameters: one workgroup = one input feature i (owns dW[i,:,:] and dlin_w[:,i]).
+__global__ __launch_bounds__(256) void kan_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ knots,
+                                                         const float* __restrict__ y, const float* __restrict__ gy,
+                                                         float* __restrict__ dW, float* __restrict__ dlw,
+                                                         float* __restrict__ dlb, int B, int in_f, int out_f, int nk,
+                                                         int BC, int act) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_knots = smem;
+  float* s_x = s_knots + KAN_MAX_KNOTS;      // BC
+  float* s_d = s_x + BC;                     // BC * nb dense basis of feature i
+  const int tid = threadIdx.x;
+  const int nb = nk - 4;
+  const int i = blockIdx.x;
+  if (tid < nk) s_knots[tid] = knots[tid];
+  __syncthreads();
+  const float inv_h0 = 1.f / (s_knots[1] - s_knots[0]);
+  const int n_sp = out_f * nb;
+  const int n_items = n_sp + out_f + (i == 0 ? out_f : 0);
+  for (int c0 = 0; c0 < B; c0 += BC) {
+    const int nbatch = min(BC, B - c0);
+    __syncthreads();
+    for (int bl = tid; bl < nbatch; bl += 256) {
+      const float xv = x[(size_t)(c0 + bl) * in_f + i];
+      const Basis4 bs = kan_basis<false>(tanhf(xv), s_knots, nk, inv_h0, nullptr);
+      float* row = s_d + bl * nb;
+      for (int k = 0; k < nb; ++k) row[k] = 0.f;
+      if (bs.j >= 0) {
+        row[bs.j] = bs.v[0];
+        if (bs.j >= 1) row[bs.j - 1] = bs.v[1];
+        if (bs.j >= 2) row[bs.j - 2] = bs.v[2];
+        if (bs.j >= 3) row[bs.j - 3] = bs.v[3];
+      }
+      s_x[bl] = xv;
+    }
+    __syncthreads();
+    for (int e = tid; e < n_items; e += 256) {
+      int o, k = -1, kind;                    // kind 0: spline weight, 1: linear weight, 2: linear bias
+      if (e < n_sp) { kind = 0; k = e / out_f; o = e - k * out_f; }
+      else if (e < n_sp + out_f) { kind = 1; o = e - n_sp; }
+      else { kind = 2; o = e - n_sp - out_f; }
+      float acc = 0.f;
+      for (int bl = 0; bl < nbatch; ++bl) {
+        const size_t q = (size_t)(c0 + bl) * out_f + o;
+        const float g = act_grad(gy[q], y[q], act);
+        const float m = kind == 0 ? s_d[bl * nb + k] : (kind == 1 ? s_x[bl] : 1.f);
+        acc = fmaf(g, m, acc);
+      }
+      float* p = kind == 0 ? dW + ((size_t)i * out_f + o) * nb + k : (kind == 1 ? dlw + (size_t)o * in_f + i : dlb + o);
+      *p = c0 == 0 ? acc : *p + acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small fp32 linear layers for the heads (192 -> 128 -> {4,3,1,1}); B is a few hundred rows.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lin_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, const float* __restrict__ mask,
+                                                      float* __restrict__ y, int B, int in_f, int out_f, int flags) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * out_f) return;
+  const int b = e / out_f, o = e - b * out_f;
+  const float4* xr = (const float4*)(x + (size_t)b * in_f);
+  const float4* wr = (const float4*)(w + (size_t)o * in_f);
+  float acc = bias ? bias[o] : 0.f;
+  for (int i = 0; i < in_f / 4; ++i) {
+    const float4 a = xr[i], c = wr[i];
+    acc = fmaf(a.x, c.x, acc); acc = fmaf(a.y, c.y, acc); acc = fmaf(a.z, c.z, acc); acc = fmaf(a.w, c.w, acc);
+  }
+  if (flags & ROVIT_LIN_RELU) acc = fmaxf(acc, 0.f);
+  if (mask) acc *= mask[e];
+  if (flags & ROVIT_LIN_CLAMP10) acc = fminf(fmaxf(acc, -10.f), 10.f);       // heads.py:100
+  y[e] = acc;
+}
+
+__device__ __forceinline__ float clamp_gate(float g, const float* yc, size_t idx) {
+  if (!yc) return g;
+  const float v = yc[idx];
+  return (v > -10.f && v < 10.f) ? g : 0.f;
+}
+
+// dx[b,i] (+)= (sum_o g[b,o] w[o,i]) * mul[b,i] * [pos[b,i] > 0]
+__global__ __launch_bounds__(256) void lin_bwd_dx_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                         const float* __restrict__ yclamp, const float* __restrict__ mul,
+                                                         const float* __restrict__ pos, float* __restrict__ dx, int B,
+                                                         int in_f, int out_f, int accumulate) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * in_f) return;
+  const int b = e / in_f, i = e - b * in_f;
+  float acc = 0.f;
+  for (int o = 0; o < out_f; ++o)
+    acc = fmaf(clamp_gate(g[(size_t)b * out_f + o], yclamp, (size_t)b * out_f + o), w[(size_t)o * in_f + i], acc);
+  if (mul) acc *= mul[e];
+  if (pos) acc = pos[e] > 0.f ? acc : 0.f;
+  dx[e] = accumulate ? dx[e] + acc : acc;
+}
+
+// dw[o,i] = sum_b g[b,o] x[b,i];  db[o] = sum_b g[b,o]
+__global__ __launch_bounds__(256) void lin_bwd_dw_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                         const float* __restrict__ yclamp, float* __restrict__ dw,
+                                                         float* __restrict__ db, int B, int in_f, int out_f) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= out_f * in_f) return;
+  const int o = e / in_f, i = e - o * in_f;
+  float acc = 0.f, accb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float gv = clamp_gate(g[(size_t)b * out_f + o], yclamp, (size_t)b * out_f + o);
+    acc = fmaf(gv, x[(size_t)b * in_f + i], acc);
+    accb += gv;
+  }
+  dw[e] = acc;
+  if (i == 0) db[o] = accb;
+}
+
+// dense (n, nb) basis table: the standalone form of BSplineBasis.compute_basis (models/kan.py:8-44); the input is
+// already the normalised coordinate (no tanh), as in KANLayer.plot_activation (kan.py:100-114).
+__global__ __launch_bounds__(256) void kan_basis_kernel(const float* __restrict__ xn, const float* __restrict__ knots,
+                                                        float* __restrict__ out, int n, int nk) {
+  __shared__ float s_knots[KAN_MAX_KNOTS];
+  if (threadIdx.x < nk) s_knots[threadIdx.x] = knots[threadIdx.x];
+  __syncthreads();
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int nb = nk - 4;
+  const Basis4 bs = kan_basis<false>(xn[e], s_knots, nk, 1.f / (s_knots[1] - s_knots[0]), nullptr);
+  float* row = out + (size_t)e * nb;
+  for (int k = 0; k < nb; ++k) row[k] = 0.f;
+  if (bs.j >= 0) {
+    row[bs.j] = bs.v[0];
+    if (bs.j >= 1) row[bs.j - 1] = bs.v[1];
+    if (bs.j >= 2) row[bs.j - 2] = bs.v[2];
+    if (bs.j >= 3) row[bs.j - 3] = bs.v[3];
+  }
+}
+
+int kan_tb(int out_f) { int tb = 256 / (out_f > 0 ? out_f : 1); return tb < 1 ? 1 : (tb > 16 ? 16 : tb); }
+
+}  // namespace
+
+extern "C" int rovit_kan_basis(const float* x_norm, const float* knots, float* basis, int n, int n_knots, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(x_norm && knots && basis, ROVIT_ERR_NULL, "kan_basis: null pointer");
+  ROVIT_CHECK_ARG(n > 0 && n_knots >= 8 && n_knots <= KAN_MAX_KNOTS, ROVIT_ERR_SHAPE, "kan_basis: bad shape n=%d knots=%d", n, n_knots);
+  hipLaunchKernelGGL(kan_basis_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x_norm, knots, basis, n, n_knots);
+  ROVIT_CHECK_LAUNCH("kan_basis_kernel");
+  return ROVIT_OK;
+}
+
+extern "C" int rovit_kan_layer_fwd(const float* x, const float* spline_w, const float* knots, const float* lin_w,
+                                   const float* lin_b, float* out, int batch, int in_f, int out_f, int n_knots, int act,
+                                   rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(x && spline_w && knots && lin_w && lin_b && out, ROVIT_ERR_NULL, "kan_layer_fwd: null pointer");
+  ROVIT_CHECK_ARG(batch > 0 && in_f > 0 && out_f > 0, ROVIT_ERR_SHAPE, "kan_layer_fwd: bad shape B=%d in=%d out=%d", batch, in_f, out_f);
+  ROVIT_CHECK_ARG(n_knots >= 8 && n_knots <= KAN_MAX_KNOTS, ROVIT_ERR_SHAPE,
+                  "kan_layer_fwd: degree-3 layer needs 8..%d knots, got %d", KAN_MAX_KNOTS, n_knots);
+  const int tb = kan_tb(out_f);
+  const size_t lds = (KAN_MAX_KNOTS + (size_t)tb * in_f * 6) * sizeof(float);
+  ROVIT_CHECK_ARG(lds <= 64 * 1024, ROVIT_ERR_SHAPE, "kan_layer_fwd: in_features %d too large for the LDS tile", in_f);
+  hipLaunchKernelGGL(kan_fwd_kernel, dim3((batch + tb - 1) / tb), dim3(256), lds, (hipStream_t)stream, x, spline_w, knots,
+                     lin_w, lin_b, out, batch, in_f, out_f, n_knots, tb, act);
+  ROVIT_CHECK_LAUNCH("kan_fwd_kernel");
+  return ROVIT_OK;
+}
+
+extern "C" int rovit_kan_layer_bwd(const float* x, const float* spline_w, const float* knots, const float* lin_w,
+                                   const float* out, const float* grad_out, float* dx, float* d_spline_w, float* d_lin_w,
+                                   float* d_lin_b, int batch, int in_f, int out_f, int n_knots, int act, int accumulate_dx,
+                                   rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(x && spline_w && knots && lin_w && out && grad_out, ROVIT_ERR_NULL, "kan_layer_bwd: null pointer");
+  ROVIT_CHECK_ARG(batch > 0 && in_f > 0 && out_f > 0, ROVIT_ERR_SHAPE, "kan_layer_bwd: bad shape");
+  ROVIT_CHECK_ARG(n_knots >= 8 && n_knots <= KAN_MAX_KNOTS, ROVIT_ERR_SHAPE, "kan_layer_bwd: bad knot count %d", n_knots);
+  if (dx) {
+    const int tb = kan_tb(out_f);
+    const size_t lds = (KAN_MAX_KNOTS + (size_t)tb * out_f) * sizeof(float);
+    hipLaunchKernelGGL(kan_bwd_dx_kernel, dim3((batch + tb - 1) / tb), dim3(256), lds, (hipStream_t)stream, x, spline_w,
+                       knots, lin_w, out, grad_out, dx, batch, in_f, out_f, n_knots, tb, act, accumulate_dx);
+    ROVIT_CHECK_LAUNCH("kan_bwd_dx_kernel");
+  }
+  if (d_spline_w) {
+    ROVIT_CHECK_ARG(d_lin_w && d_lin_b, ROVIT_ERR_NULL, "kan_layer_bwd: parameter gradients must be given together");
+    const int nb = n_knots - 4;
+    int bc = (20 * 1024) / nb;                 // dense basis rows kept in LDS (<= 80 KB)
+    bc = bc > batch ? batch : bc;
+    const size_t lds = (KAN_MAX_KNOTS + (size_t)bc * (nb + 1)) * sizeof(float);
+    hipLaunchKernelGGL(kan_bwd_dw_kernel, dim3(in_f), dim3(256), lds, (hipStream_t)stream, x, knots, out, grad_out,
+                       d_spline_w, d_lin_w, d_lin_b, batch, in_f, out_f, n_knots, bc, act);
+    ROVIT_CHECK_LAUNCH("kan_bwd_dw_kernel");
+  }
+  return ROVIT_OK;
+}
+
+extern "C" int rovit_linear_fwd(const float* x, const float* w, const float* bias, const float* mask, float* y, int batch,
+                                int in_f, int out_f, int flags, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(x && w && y, ROVIT_ERR_NULL, "linear_fwd: null pointer");
+  ROVIT_CHECK_ARG(batch > 0 && in_f > 0 && out_f > 0 && in_f % 4 == 0, ROVIT_ERR_SHAPE, "linear_fwd: bad shape (in %% 4)");
+  ROVIT_CHECK_ARG(rovit_aligned16(x) && rovit_aligned16(w), ROVIT_ERR_ALIGN, "linear_fwd: x/w must be 16-byte aligned");
+  const int n = batch * out_f;
+  hipLaunchKernelGGL(lin_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, w, bias, mask, y, batch,
+                     in_f, out_f, flags);
+  ROVIT_CHECK_LAUNCH("lin_fwd_kernel");
+  return ROVIT_OK;
+}
+
+extern "C" int rovit_linear_bwd(const float* x, const float* w, const float* grad_y, const float* y_clamped,
+                                const float* dx_mul, const float* dx_pos, float* dx, float* dw, float* db, int batch,
+                                int in_f, int out_f, int accumulate_dx, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(x && w && grad_y, ROVIT_ERR_NULL, "linear_bwd: null pointer");
+  ROVIT_CHECK_ARG(batch > 0 && in_f > 0 && out_f > 0, ROVIT_ERR_SHAPE, "linear_bwd: bad shape");
+  if (dx) {
+    const int n = batch * in_f;
+    hipLaunchKernelGGL(lin_bwd_dx_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, grad_y, w, y_clamped,
+                       dx_mul, dx_pos, dx, batch, in_f, out_f, accumulate_dx);
+    ROVIT_CHECK_LAUNCH("lin_bwd_dx_kernel");
+  }
+  if (dw) {
+    ROVIT_CHECK_ARG(db, ROVIT_ERR_NULL, "linear_bwd: dw and db must be given together");
+    const int n = out_f * in_f;
+    hipLaunchKernelGGL(lin_bwd_dw_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, grad_y, x, y_clamped,
+                       dw, db, batch, in_f, out_f);
+    ROVIT_CHECK_LAUNCH("lin_bwd_dw_kernel");
+  }
+  return ROVIT_OK;
+}
+
+// ---- the three heads as one call (models/rovit_kan.py:93-116) --------------------------------------
+// params (fp32, reference layouts): [0] cls.fc1.w [1] cls.fc1.b [2] cls.fc2.w [3] cls.fc2.b
+//   [4] ord.fc1.w [5] ord.fc1.b [6] ord.fc2.w [7] ord.fc2.b
+//   [8] unc.fc1.w [9] unc.fc1.b [10] unc.fc_mu.w [11] unc.fc_mu.b [12] unc.fc_logvar.w [13] unc.fc_logvar.b
+// hidden: (3, B, hid) post-ReLU/dropout activations (saved for backward).  masks[h] may be NULL (eval).
+extern "C" int rovit_heads_fwd(const float* features, const float* const* params, const float* const* masks, float* hidden,
+                               float* cls_logits, float* ordinal_logits, float* mu, float* log_var, int batch, int embed,
+                               int hid, int num_classes, int stage, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(features && params && hidden && cls_logits, ROVIT_ERR_NULL, "heads_fwd: null pointer");
+  ROVIT_CHECK_ARG(stage >= 1 && stage <= 4, ROVIT_ERR_SHAPE, "heads_fwd: curriculum stage %d not in 1..4", stage);
+  const size_t hs = (size_t)batch * hid;
+  int rc;
+#define RUN(call) do { rc = (call); if (rc != ROVIT_OK) return rc; } while (0)
+  RUN(rovit_linear_fwd(features, params[0], params[1], masks ? masks[0] : nullptr, hidden, batch, embed, hid, ROVIT_LIN_RELU, stream));
+  RUN(rovit_linear_fwd(hidden, params[2], params[3], nullptr, cls_logits, batch, hid, num_classes, 0, stream));
+  if (stage >= 2) {
+    ROVIT_CHECK_ARG(ordinal_logits, ROVIT_ERR_NULL, "heads_fwd: ordinal_logits is NULL at stage %d", stage);
+    RUN(rovit_linear_fwd(features, params[4], params[5], masks ? masks[1] : nullptr, hidden + hs, batch, embed, hid, ROVIT_LIN_RELU, stream));
+    RUN(rovit_linear_fwd(hidden + hs, params[6], params[7], nullptr, ordinal_logits, batch, hid, num_classes - 1, 0, stream));
+  }
+  if (stage >= 3) {
+    ROVIT_CHECK_ARG(mu && log_var, ROVIT_ERR_NULL, "heads_fwd: mu/log_var is NULL at stage %d", stage);
+    RUN(rovit_linear_fwd(features, params[8], params[9], masks ? masks[2] : nullptr, hidden + 2 * hs, batch, embed, hid, ROVIT_LIN_RELU, stream));
+    RUN(rovit_linear_fwd(hidden + 2 * hs, params[10], params[11], nullptr, mu, batch, hid, 1, 0, stream));
+    RUN(rovit_linear_fwd(hidden + 2 * hs, params[12], params[13], nullptr, log_var, batch, hid, 1, ROVIT_LIN_CLAMP10, stream));
+  }
+  return ROVIT_OK;
+}
+
+// grads[] mirrors params[]; g_* may be NULL (head inactive or output unused); log_var is the clamped forward output.
+// scratch: (B, hid) floats.  d_features is overwritten (accumulate_dfeat == 0) or accumulated into.
+extern "C" int rovit_heads_bwd(const float* features, const float* const* params, const float* const* masks,
+                               const float* hidden, const float* log_var, const float* g_cls, const float* g_ord,
+                               const float* g_mu, const float* g_lv, float* d_features, float* const* grads, float* scratch,
+                               int batch, int embed, int hid, int num_classes, int accumulate_dfeat, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(features && params && hidden && grads && scratch && d_features, ROVIT_ERR_NULL, "heads_bwd: null pointer");
+  const size_t hs = (size_t)batch * hid;
+  int rc;
+  int acc = accumulate_dfeat;
+  if (g_cls) {
+    RUN(rovit_linear_bwd(hidden, params[2], g_cls, nullptr, masks ? masks[0] : nullptr, hidden, scratch, grads[2], grads[3], batch, hid, num_classes, 0, stream));
+    RUN(rovit_linear_bwd(features, params[0], scratch, nullptr, nullptr, nullptr, d_features, grads[0], grads[1], batch, embed, hid, acc, stream));
+    acc = 1;
+  }
+  if (g_ord) {
+    RUN(rovit_linear_bwd(hidden + hs, params[6], g_ord, nullptr, masks ? masks[1] : nullptr, hidden + hs, scratch, grads[6], grads[7], batch, hid, num_classes - 1, 0, stream));
+    RUN(rovit_linear_bwd(features, params[4], scratch, nullptr, nullptr, nullptr, d_features, grads[4], grads[5], batch, embed, hid, acc, stream));
+    acc = 1;
+  }
+  if (g_mu || g_lv) {
+    ROVIT_CHECK_ARG(g_mu && g_lv && log_var, ROVIT_ERR_NULL, "heads_bwd: mu and log_var gradients come together");
+    const float* m2 = masks ? masks[2] : nullptr;
+    RUN(rovit_linear_bwd(hidden + 2 * hs, params[10], g_mu, nullptr, m2, hidden + 2 * hs, scratch, grads[10], grads[11], batch, hid, 1, 0, stream));
+    RUN(rovit_linear_bwd(hidden + 2 * hs, params[12], g_lv, log_var, m2, hidden + 2 * hs, scratch, grads[12], grads[13], batch, hid, 1, 1, stream));
+    RUN(rovit_linear_bwd(features, params[8], scratch, nullptr, nullptr, nullptr, d_features, grads[8], grads[9], batch, embed, hid, acc, stream));
+    acc = 1;
+  }
+#undef RUN
+  if (!acc) {
+    hipError_t e = hipMemsetAsync(d_features, 0, (size_t)batch * embed * sizeof(float), (hipStream_t)stream);
+    ROVIT_CHECK_ARG(e == hipSuccess, ROVIT_ERR_LAUNCH, "heads_bwd: memset failed");
+  }
+  return ROVIT_OK;
+}

@@ -1,0 +1,230 @@
+// DeiT-Tiny backbone forward / backward: the launch sequence over the kernels in gemm.hip, attention.hip and
+// elementwise.hip.  Everything is enqueued on the caller's stream; nothing here allocates or synchronises.
+//
+// Reference being restated: DeiTTinyBackbone.forward (/root/reference/models/backbone.py:23-25) ->
+// timm VisionTransformer.forward, and its autograd backward (training/trainer.py:119,136).
+//
+// Data layout in HBM (B images, T = 197 tokens, M = B*T rows):
+//   X      fp32 (M,192)   residual stream, updated in place by the proj / fc2 epilogues
+//   per block, kept for backward when training: xhat1/xhat2 bf16 (M,192) + rstd (M), qkv bf16 (M,576),
+//   attention out bf16 (M,192) + lse2 (B,3,T), act = gelu(pre) and dact = gelu'(pre) bf16 (M,768)
+//   LayerNorm affines are folded into the following Linear (W*gamma, b + W beta) by rovit_vit_prepare, so the
+//   GEMM operand is the normalised xhat itself and the wgrad recovers dgamma/dbeta from G = dY^T xhat.
+#include "common.h"
+
+namespace {
+
+constexpr int T = 197, D = 192, H = 3, MLP = 768, PD = 768;
+enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_MUL = 3, EPI_PATCH = 4 };
+enum { P_CLS = 0, P_POS, P_PATCH_W, P_PATCH_B, P_NORM_W, P_NORM_B, P_BLOCK0 };
+enum { B_N1W = 0, B_N1B, B_QKVW, B_QKVB, B_PROJW, B_PROJB, B_N2W, B_N2B, B_FC1W, B_FC1B, B_FC2W, B_FC2B, B_COUNT };
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Prep {          // byte offsets into the prepared-weight buffer
+  size_t wpe;
+  size_t blk0, blk_stride;
+  size_t wqkv, wqkvT, wproj, wprojT, wfc1, wfc1T, wfc2, wfc2T, bqkv, bfc1;   // offsets inside one block
+  size_t total;
+  explicit Prep(int depth) {
+    size_t o = 0;
+    wpe = o; o = al(o + (size_t)D * PD * 2);
+    blk0 = o;
+    size_t b = 0;
+    wqkv = b; b = al(b + (size_t)3 * D * D * 2);
+    wqkvT = b; b = al(b + (size_t)3 * D * D * 2);
+    wproj = b; b = al(b + (size_t)D * D * 2);
+    wprojT = b; b = al(b + (size_t)D * D * 2);
+    wfc1 = b; b = al(b + (size_t)MLP * D * 2);
+    wfc1T = b; b = al(b + (size_t)MLP * D * 2);
+    wfc2 = b; b = al(b + (size_t)MLP * D * 2);
+    wfc2T = b; b = al(b + (size_t)MLP * D * 2);
+    bqkv = b; b = al(b + (size_t)3 * D * 4);
+    bfc1 = b; b = al(b + (size_t)MLP * 4);
+    blk_stride = b;
+    total = blk0 + (size_t)depth * blk_stride;
+  }
+};
+
+struct Plan {          // byte offsets into the workspace
+  int B, depth, training;
+  size_t M;
+  size_t X, col, xhat_cls, rstd_cls;
+  size_t blk0, blk_stride;
+  size_t xhat1, rstd1, qkv, lse, o, xhat2, rstd2, act, dact;   // inside one block
+  // backward temporaries
+  size_t dX, dXb, dpre, dxhat, dO, dqkv;
+  size_t slab_qkv, slab_proj, slab_fc1, slab_fc2, slab_pe, gscr;
+  int s_qkv, s_proj, s_fc1, s_fc2, s_pe;
+  size_t total;
+  Plan(int batch, int depth_, int training_) : B(batch), depth(depth_), training(training_) {
+    M = (size_t)B * T;
+    size_t o = 0;
+    X = o; o = al(o + M * D * 4);
+    col = o; o = al(o + (size_t)B * (T - 1) * PD * 2);
+    xhat_cls = o; o = al(o + (size_t)B * D * 4);
+    rstd_cls = o; o = al(o + (size_t)B * 4);
+    size_t b = 0;
+    xhat1 = b; b = al(b + M * D * 2);
+    rstd1 = b; b = al(b + M * 4);
+    qkv = b; b = al(b + M * 3 * D * 2);
+    lse = b; b = al(b + (size_t)B * H * T * 4);
+    this->o = b; b = al(b + M * D * 2);
+    xhat2 = b; b = al(b + M * D * 2);
+    rstd2 = b; b = al(b + M * 4);
+    act = b; b = al(b + M * MLP * 2);
+    dact = b; b = al(b + M * MLP * 2);
+    blk_stride = training ? b : 0;              // inference: every block reuses the same buffers
+    blk0 = o; o += training ? (size_t)depth * b : b;
+    s_qkv = rovit_wgrad_splits((int)M, 3 * D, D);
+    s_proj = rovit_wgrad_splits((int)M, D, D);
+    s_fc1 = rovit_wgrad_splits((int)M, MLP, D);
+    s_fc2 = rovit_wgrad_splits((int)M, D, MLP);
+    s_pe = rovit_wgrad_splits(B * (T - 1), D, PD);
+    if (training) {
+      dX = o; o = al(o + M * D * 4);
+      dXb = o; o = al(o + M * D * 2);
+      dpre = o; o = al(o + M * MLP * 2);
+      dxhat = o; o = al(o + M * D * 2);
+      dO = o; o = al(o + M * D * 2);
+      dqkv = o; o = al(o + M * 3 * D * 2);
+      slab_qkv = o; o = al(o + rovit_wgrad_workspace_bytes(3 * D, D, s_qkv));
+      slab_proj = o; o = al(o + rovit_wgrad_workspace_bytes(D, D, s_proj));
+      slab_fc1 = o; o = al(o + rovit_wgrad_workspace_bytes(MLP, D, s_fc1));
+      slab_fc2 = o; o = al(o + rovit_wgrad_workspace_bytes(D, MLP, s_fc2));
+      slab_pe = o; o = al(o + rovit_wgrad_workspace_bytes(D, PD, s_pe));
+      gscr = o; o = al(o + (size_t)MLP * D * 4);
+    }
+    total = o;
+  }
+};
+
+#define RUN(call) do { int rc__ = (call); if (rc__ != ROVIT_OK) return rc__; } while (0)
+
+int check_common(const void* params, const void* prep, const void* ws, int batch, int depth) {
+  ROVIT_CHECK_ARG(params && prep && ws, ROVIT_ERR_NULL, "vit: null params/prep/workspace");
+  ROVIT_CHECK_ARG(batch > 0 && depth > 0 && depth <= 64, ROVIT_ERR_SHAPE, "vit: bad batch %d / depth %d", batch, depth);
+  ROVIT_CHECK_ARG(rovit_aligned16(prep) && rovit_aligned16(ws), ROVIT_ERR_ALIGN, "vit: prep/workspace must be 16-byte aligned");
+  return ROVIT_OK;
+}
+
+}  // namespace
+
+extern "C" size_t rovit_vit_prep_bytes(int depth) { return Prep(depth).total; }
+extern "C" size_t rovit_vit_workspace_bytes(int batch, int depth, int training) { return Plan(batch, depth, training).total; }
+extern "C" int rovit_vit_num_params(int depth) { return P_BLOCK0 + B_COUNT * depth; }
+
+// Fold the LayerNorm affines, cast to bf16 and build the transposed copies the dgrad GEMMs read.
+// Must be re-run whenever the fp32 parameters change (every optimizer step).
+extern "C" int rovit_vit_prepare(const float* const* params, void* prep, int depth, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(params && prep && depth > 0, ROVIT_ERR_NULL, "vit_prepare: null pointer");
+  const Prep P(depth);
+  char* pb = (char*)prep;
+  RUN(rovit_prep_weight(params[P_PATCH_W], nullptr, nullptr, nullptr, pb + P.wpe, nullptr, nullptr, D, PD, stream));
+  for (int i = 0; i < depth; ++i) {
+    const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
+    char* q = pb + P.blk0 + (size_t)i * P.blk_stride;
+    RUN(rovit_prep_weight(bp[B_QKVW], bp[B_QKVB], bp[B_N1W], bp[B_N1B], q + P.wqkv, q + P.wqkvT, (float*)(q + P.bqkv), 3 * D, D, stream));
+    RUN(rovit_prep_weight(bp[B_PROJW], nullptr, nullptr, nullptr, q + P.wproj, q + P.wprojT, nullptr, D, D, stream));
+    RUN(rovit_prep_weight(bp[B_FC1W], bp[B_FC1B], bp[B_N2W], bp[B_N2B], q + P.wfc1, q + P.wfc1T, (float*)(q + P.bfc1), MLP, D, stream));
+    RUN(rovit_prep_weight(bp[B_FC2W], nullptr, nullptr, nullptr, q + P.wfc2, q + P.wfc2T, nullptr, D, MLP, stream));
+  }
+  return ROVIT_OK;
+}
+
+// images fp32 NCHW (B,3,224,224) -> features fp32 (B,192)
+extern "C" int rovit_vit_forward(const float* images, const float* const* params, const void* prep, void* workspace,
+                                 float* features, int batch, int depth, int training, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(images && features, ROVIT_ERR_NULL, "vit_forward: null images/features");
+  RUN(check_common(params, prep, workspace, batch, depth));
+  const Prep P(depth);
+  const Plan L(batch, depth, training);
+  const char* pb = (const char*)prep;
+  char* ws = (char*)workspace;
+  float* X = (float*)(ws + L.X);
+  const int M = (int)L.M;
+  const float eps = 1e-6f;
+  RUN(rovit_im2col(images, ws + L.col, batch, stream));
+  RUN(rovit_cls_rows(params[P_CLS], params[P_POS], X, batch, T, stream));
+  RUN(rovit_gemm_nt(ws + L.col, PD, pb + P.wpe, PD, batch * (T - 1), D, PD, params[P_PATCH_B], EPI_PATCH, nullptr, 0, nullptr, X, D,
+                    nullptr, 0, params[P_POS], T, stream));
+  for (int i = 0; i < depth; ++i) {
+    const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
+    const char* q = pb + P.blk0 + (size_t)i * P.blk_stride;
+    char* s = ws + L.blk0 + (size_t)i * L.blk_stride;
+    RUN(rovit_layernorm_fwd(X, s + L.xhat1, (float*)(s + L.rstd1), M, D, eps, stream));
+    RUN(rovit_gemm_nt(s + L.xhat1, D, q + P.wqkv, D, M, 3 * D, D, (const float*)(q + P.bqkv), EPI_BF16, s + L.qkv, 3 * D, nullptr,
+                      nullptr, 0, nullptr, 0, nullptr, 0, stream));
+    RUN(rovit_attention_fwd(s + L.qkv, s + L.o, (float*)(s + L.lse), batch, T, H, D / H, 0.125f, stream));
+    RUN(rovit_gemm_nt(s + L.o, D, q + P.wproj, D, M, D, D, bp[B_PROJB], EPI_RESID, nullptr, 0, nullptr, X, D, nullptr, 0, nullptr, 0, stream));
+    RUN(rovit_layernorm_fwd(X, s + L.xhat2, (float*)(s + L.rstd2), M, D, eps, stream));
+    RUN(rovit_gemm_nt(s + L.xhat2, D, q + P.wfc1, D, M, MLP, D, (const float*)(q + P.bfc1), EPI_GELU, s + L.act, MLP,
+                      training ? s + L.dact : nullptr, nullptr, 0, nullptr, 0, nullptr, 0, stream));
+    RUN(rovit_gemm_nt(s + L.act, MLP, q + P.wfc2, MLP, M, D, MLP, bp[B_FC2B], EPI_RESID, nullptr, 0, nullptr, X, D, nullptr, 0, nullptr, 0, stream));
+  }
+  RUN(rovit_cls_norm_fwd(X, params[P_NORM_W], params[P_NORM_B], features, (float*)(ws + L.xhat_cls), (float*)(ws + L.rstd_cls), batch,
+                         T, eps, stream));
+  return ROVIT_OK;
+}
+
+// Backward over blocks first_block, first_block-1, ..., last_block (inclusive).  first_block == depth-1 also
+// runs the final-norm backward from d_features; last_block == 0 also produces the patch-embed / pos / cls
+// gradients.  Splitting the range lets the caller start a gradient all-reduce between calls.
+// grads[] mirrors params[]; every entry of the processed range is overwritten.
+extern "C" int rovit_vit_backward(const float* d_features, const float* const* params, const void* prep, void* workspace,
+                                  float* const* grads, int batch, int depth, int first_block, int last_block,
+                                  rovit_stream_t stream) {
+  RUN(check_common(params, prep, workspace, batch, depth));
+  ROVIT_CHECK_ARG(grads, ROVIT_ERR_NULL, "vit_backward: null grads");
+  ROVIT_CHECK_ARG(first_block < depth && last_block >= 0 && first_block >= last_block, ROVIT_ERR_SHAPE,
+                  "vit_backward: bad block range [%d..%d] for depth %d", first_block, last_block, depth);
+  const Prep P(depth);
+  const Plan L(batch, depth, 1);
+  const char* pb = (const char*)prep;
+  char* ws = (char*)workspace;
+  const int M = (int)L.M;
+  float* dX = (float*)(ws + L.dX);
+  char* dXb = ws + L.dXb;
+  if (first_block == depth - 1) {
+    ROVIT_CHECK_ARG(d_features, ROVIT_ERR_NULL, "vit_backward: null d_features");
+    RUN(rovit_cls_norm_bwd(d_features, (const float*)(ws + L.xhat_cls), (const float*)(ws + L.rstd_cls), params[P_NORM_W], dX, dXb,
+                           grads[P_NORM_W], grads[P_NORM_B], batch, T, stream));
+  }
+  for (int i = first_block; i >= last_block; --i) {
+    const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
+    float* const* bg = grads + P_BLOCK0 + B_COUNT * i;
+    const char* q = pb + P.blk0 + (size_t)i * P.blk_stride;
+    char* s = ws + L.blk0 + (size_t)i * L.blk_stride;
+    // ---- MLP ----
+    RUN(rovit_gemm_nt(dXb, D, q + P.wfc2T, D, M, MLP, D, nullptr, EPI_MUL, ws + L.dpre, MLP, nullptr, nullptr, 0, s + L.dact, MLP,
+                      nullptr, 0, stream));
+    RUN(rovit_wgrad(dXb, D, s + L.act, MLP, M, D, MLP, L.s_fc2, 0, (float*)(ws + L.slab_fc2), stream));
+    RUN(rovit_wgrad_reduce((const float*)(ws + L.slab_fc2), L.s_fc2, D, MLP, nullptr, nullptr, nullptr, bg[B_FC2W], bg[B_FC2B], nullptr,
+                           nullptr, nullptr, stream));
+    RUN(rovit_gemm_nt(ws + L.dpre, MLP, q + P.wfc1T, MLP, M, D, MLP, nullptr, EPI_BF16, ws + L.dxhat, D, nullptr, nullptr, 0, nullptr, 0,
+                      nullptr, 0, stream));
+    RUN(rovit_wgrad(ws + L.dpre, MLP, s + L.xhat2, D, M, MLP, D, L.s_fc1, 0, (float*)(ws + L.slab_fc1), stream));
+    RUN(rovit_wgrad_reduce((const float*)(ws + L.slab_fc1), L.s_fc1, MLP, D, bp[B_N2W], bp[B_N2B], bp[B_FC1W], bg[B_FC1W], bg[B_FC1B],
+                           bg[B_N2W], bg[B_N2B], (float*)(ws + L.gscr), stream));
+    RUN(rovit_layernorm_bwd(ws + L.dxhat, s + L.xhat2, (const float*)(s + L.rstd2), dX, dXb, M, D, stream));
+    // ---- attention ----
+    RUN(rovit_gemm_nt(dXb, D, q + P.wprojT, D, M, D, D, nullptr, EPI_BF16, ws + L.dO, D, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, stream));
+    RUN(rovit_wgrad(dXb, D, s + L.o, D, M, D, D, L.s_proj, 0, (float*)(ws + L.slab_proj), stream));
+    RUN(rovit_wgrad_reduce((const float*)(ws + L.slab_proj), L.s_proj, D, D, nullptr, nullptr, nullptr, bg[B_PROJW], bg[B_PROJB], nullptr,
+                           nullptr, nullptr, stream));
+    RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, ws + L.dqkv, batch, T, H, D / H, 0.125f, stream));
+    RUN(rovit_gemm_nt(ws + L.dqkv, 3 * D, q + P.wqkvT, 3 * D, M, D, 3 * D, nullptr, EPI_BF16, ws + L.dxhat, D, nullptr, nullptr, 0, nullptr,
+                      0, nullptr, 0, stream));
+    RUN(rovit_wgrad(ws + L.dqkv, 3 * D, s + L.xhat1, D, M, 3 * D, D, L.s_qkv, 0, (float*)(ws + L.slab_qkv), stream));
+    RUN(rovit_wgrad_reduce((const float*)(ws + L.slab_qkv), L.s_qkv, 3 * D, D, bp[B_N1W], bp[B_N1B], bp[B_QKVW], bg[B_QKVW], bg[B_QKVB],
+                           bg[B_N1W], bg[B_N1B], (float*)(ws + L.gscr), stream));
+    RUN(rovit_layernorm_bwd(ws + L.dxhat, s + L.xhat1, (const float*)(s + L.rstd1), dX, dXb, M, D, stream));
+  }
+  if (last_block == 0) {
+    RUN(rovit_wgrad(dXb, D, ws + L.col, PD, batch * (T - 1), D, PD, L.s_pe, T, (float*)(ws + L.slab_pe), stream));
+    RUN(rovit_wgrad_reduce((const float*)(ws + L.slab_pe), L.s_pe, D, PD, nullptr, nullptr, nullptr, grads[P_PATCH_W], grads[P_PATCH_B],
+                           nullptr, nullptr, nullptr, stream));
+    RUN(rovit_pos_grad(dX, grads[P_POS], grads[P_CLS], batch, T, stream));
+  }
+  return ROVIT_OK;
+}

@@ -1,0 +1,85 @@
+"""KAN severity head on the HIP path.  Mirrors /root/reference/models/kan.py (BSplineBasis :8-44,
+KANLayer :47-114, KANSeverityModule :117-170): same constructors, attributes, parameter/buffer names."""
+from typing import List, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from rovit_hip import native
+from rovit_hip.functions import ACT_NONE, ACT_RELU, ACT_SIGMOID3, KANLayerFn
+
+
+def _check_degree(degree: int):
+    if degree != 3:
+        raise NotImplementedError('the HIP KAN kernels implement the cubic (degree=3) basis the reference configures '
+                                  '(configs/config.py:65)')
+
+
+class BSplineBasis:
+    @staticmethod
+    def compute_basis(x: torch.Tensor, knots: torch.Tensor, degree: int = 3) -> torch.Tensor:
+        """(B, dim) normalised inputs -> (B, dim, num_basis) truncated cubic basis (reference kan.py:8-44)."""
+        _check_degree(degree)
+        xf = x.detach().float().contiguous()
+        kf = knots.detach().float().contiguous()
+        nb = kf.numel() - degree - 1
+        out = torch.empty(xf.numel(), nb, device=xf.device, dtype=torch.float32)
+        native.call('rovit_kan_basis', native.ptr(xf), native.ptr(kf), native.ptr(out), xf.numel(), kf.numel(),
+                    native.stream_ptr())
+        return out.view(*x.shape, nb)
+
+
+class KANLayer(nn.Module):
+    def __init__(self, in_features: int, out_features: int, num_knots: int = 5, degree: int = 3):
+        super().__init__()
+        _check_degree(degree)
+        self.in_features, self.out_features = in_features, out_features
+        self.num_knots, self.degree = num_knots, degree
+        self.num_basis = num_knots + degree - 1
+        self.register_buffer('knots', torch.linspace(-1, 1, num_knots + 2 * degree))
+        self.spline_weights = nn.Parameter(torch.randn(in_features, out_features, self.num_basis) * 0.1)
+        self.linear = nn.Linear(in_features, out_features, bias=True)
+
+    def _run(self, x: torch.Tensor, act: int) -> torch.Tensor:
+        return KANLayerFn.apply(x, self.spline_weights, self.knots, self.linear.weight, self.linear.bias, act)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._run(x, ACT_NONE)
+
+    def get_spline_weights(self) -> torch.Tensor:
+        return self.spline_weights.detach()
+
+    def plot_activation(self, input_idx: int = 0, output_idx: int = 0, num_points: int = 100) -> Tuple[np.ndarray, np.ndarray]:
+        xs = torch.linspace(-1, 1, num_points, device=self.knots.device)
+        basis = BSplineBasis.compute_basis(xs.unsqueeze(0), self.knots, self.degree)[0]
+        ys = (basis * self.spline_weights[input_idx, output_idx].detach()).sum(dim=1)
+        return xs.cpu().numpy(), ys.cpu().numpy()
+
+
+class KANSeverityModule(nn.Module):
+    def __init__(self, layers: List[int] = [384, 64, 16, 1], num_knots: int = 5, degree: int = 3):
+        super().__init__()
+        self.layers_dims, self.num_knots, self.degree = layers, num_knots, degree
+        self.kan_layers = nn.ModuleList(KANLayer(a, b, num_knots, degree) for a, b in zip(layers[:-1], layers[1:]))
+        self.activations = nn.ModuleList(nn.ReLU() for _ in range(len(layers) - 2))
+
+    def _trajectory(self, x: torch.Tensor) -> List[torch.Tensor]:
+        acts = [x]
+        last = len(self.kan_layers) - 1
+        for i, layer in enumerate(self.kan_layers):      # activation fused into the layer kernel
+            x = layer._run(x, ACT_SIGMOID3 if i == last else ACT_RELU)
+            acts.append(x)
+        return acts
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._trajectory(x)[-1]
+
+    def get_spline_weights(self) -> List[torch.Tensor]:
+        return [layer.get_spline_weights() for layer in self.kan_layers]
+
+    def get_activation_trajectory(self, x: torch.Tensor) -> List[torch.Tensor]:
+        return self._trajectory(x)
+
+    def count_parameters(self) -> int:
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)

@@ -1,0 +1,107 @@
+"""RoViT-KAN on the HIP path.  Mirrors /root/reference/models/rovit_kan.py (:9-181): constructor (config object or
+scalars, plus the ``embed_dim=`` keyword the reference's own callers use: scripts/train.py:88-97,
+evaluation/evaluator.py:233-242), curriculum-stage gate, 6-key output dict, predict/freeze/count helpers."""
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from rovit_hip.functions import HeadsFn
+
+from .backbone import DeiTTinyBackbone
+from .heads import ClassificationHead, OrdinalHead, UncertaintyHead, dropout_mask
+from .kan import KANSeverityModule
+
+
+class RoViTKAN(nn.Module):
+    def __init__(self, config_or_embed_dim=None, hidden_dim: int = 128, num_classes: int = 4, kan_layers: list = None,
+                 kan_num_knots: int = 5, kan_degree: int = 3, dropout: float = 0.3, pretrained: bool = True,
+                 embed_dim: int = None):
+        super().__init__()
+        if hasattr(config_or_embed_dim, 'model'):
+            cfg = config_or_embed_dim
+            embed_dim = cfg.model.embed_dim
+            hidden_dim, num_classes = cfg.model.hidden_dim, cfg.data.num_classes
+            kan_layers, kan_num_knots, kan_degree = cfg.model.kan_layers, cfg.model.kan_num_knots, cfg.model.kan_degree
+            dropout, pretrained = cfg.model.dropout, cfg.model.pretrained
+        elif config_or_embed_dim is not None:
+            embed_dim = config_or_embed_dim
+        self.backbone = DeiTTinyBackbone(pretrained=pretrained, freeze=False)
+        if embed_dim is None:
+            embed_dim = self.backbone.embed_dim
+        if kan_layers is None:
+            kan_layers = [embed_dim, 64, 16, 1]
+        self.classification_head = ClassificationHead(embed_dim, hidden_dim, num_classes, dropout)
+        self.ordinal_head = OrdinalHead(embed_dim, hidden_dim, num_classes, dropout)
+        self.uncertainty_head = UncertaintyHead(embed_dim, hidden_dim, dropout)
+        self.kan_module = KANSeverityModule(layers=kan_layers, num_knots=kan_num_knots, degree=kan_degree)
+        self._curriculum_stage = 4
+
+    @property
+    def curriculum_stage(self) -> int:
+        return self._curriculum_stage
+
+    @curriculum_stage.setter
+    def curriculum_stage(self, stage: int):
+        assert 1 <= stage <= 4, "Stage must be between 1 and 4"
+        self._curriculum_stage = stage
+
+    def _head_params(self):
+        c, o, u = self.classification_head, self.ordinal_head, self.uncertainty_head
+        return [c.fc1.weight, c.fc1.bias, c.fc2.weight, c.fc2.bias, o.fc1.weight, o.fc1.bias, o.fc2.weight, o.fc2.bias,
+                u.fc1.weight, u.fc1.bias, u.fc_mu.weight, u.fc_mu.bias, u.fc_logvar.weight, u.fc_logvar.bias]
+
+    def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        stage = self._curriculum_stage
+        features = self.backbone(x)
+        B, hid = features.shape[0], self.classification_head.fc1.out_features
+        masks = None
+        if self.training:
+            ms = [dropout_mask(h.dropout, True, (B, hid), features.device) if stage >= need else None
+                  for h, need in ((self.classification_head, 1), (self.ordinal_head, 2), (self.uncertainty_head, 3))]
+            masks = ms if any(m is not None for m in ms) else None
+        cls_logits, ordinal_logits, mu, log_var = HeadsFn.apply(features, stage, masks, *self._head_params())
+        return {
+            'cls_logits': cls_logits,
+            'features': features,
+            'ordinal_logits': ordinal_logits if stage >= 2 else None,
+            'mu': mu if stage >= 3 else None,
+            'log_var': log_var if stage >= 3 else None,
+            'kan_severity': self.kan_module(features) if stage >= 4 else None,
+        }
+
+    def predict(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        self.eval()
+        with torch.no_grad():
+            out = self.forward(x)
+            probs = torch.softmax(out['cls_logits'], dim=1)
+            pred = {'class': torch.argmax(probs, dim=1), 'class_probs': probs, 'features': out['features']}
+            if out['ordinal_logits'] is not None:
+                p = OrdinalHead.probabilities_from_logits(out['ordinal_logits'])
+                levels = torch.arange(p.shape[1], dtype=torch.float32, device=p.device)
+                pred['ordinal_probs'] = p
+                pred['ordinal_severity'] = (p * levels).sum(dim=1, keepdim=True)
+            if out['mu'] is not None:
+                pred['uncertainty_mu'] = out['mu']
+                pred['uncertainty_std'] = torch.exp(0.5 * out['log_var'])
+            if out['kan_severity'] is not None:
+                pred['kan_severity'] = out['kan_severity']
+            return pred
+
+    def freeze_backbone(self):
+        self.backbone.freeze()
+
+    def unfreeze_backbone(self):
+        self.backbone.unfreeze()
+
+    def get_attention_maps(self, x: torch.Tensor):
+        return self.backbone.get_attention_maps(x)
+
+    def count_parameters(self) -> Dict[str, int]:
+        def n(m):
+            return sum(p.numel() for p in m.parameters() if p.requires_grad)
+        counts = {'backbone': n(self.backbone), 'classification_head': n(self.classification_head),
+                  'ordinal_head': n(self.ordinal_head), 'uncertainty_head': n(self.uncertainty_head),
+                  'kan_module': n(self.kan_module)}
+        counts['total'] = sum(counts.values())
+        return counts

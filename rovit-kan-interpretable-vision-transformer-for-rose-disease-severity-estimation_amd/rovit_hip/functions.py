@@ -1,0 +1,298 @@
+"""torch.autograd.Function wrappers around the C ABI (include/rovit_hip.h).
+
+torch is used for device memory, the current stream and autograd bookkeeping only; every FLOP of the
+hot path runs in librovit_hip.so.  CPU tensors are rejected (no fallback).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import native
+from .native import call, ptr, ptr_array, stream_ptr
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID3 = 0, 1, 2
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# KAN layer  (reference: models/kan.py:70-95 + the activation applied after it, :138-149)
+# ------------------------------------------------------------------------------------------------
+class KANLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, spline_w, knots, lin_w, lin_b, act: int):
+        x, spline_w, knots, lin_w, lin_b = map(_f32c, (x, spline_w, knots, lin_w, lin_b))
+        B, in_f = x.shape
+        out_f = lin_w.shape[0]
+        out = torch.empty(B, out_f, device=x.device, dtype=torch.float32)
+        call('rovit_kan_layer_fwd', ptr(x), ptr(spline_w), ptr(knots), ptr(lin_w), ptr(lin_b), ptr(out),
+             B, in_f, out_f, knots.numel(), act, stream_ptr())
+        ctx.save_for_backward(x, spline_w, knots, lin_w, out)
+        ctx.act = act
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, spline_w, knots, lin_w, out = ctx.saved_tensors
+        g = _f32c(g)
+        B, in_f = x.shape
+        out_f = lin_w.shape[0]
+        need_dx = ctx.needs_input_grad[0]
+        need_dw = ctx.needs_input_grad[1] or ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        dx = torch.empty_like(x) if need_dx else None
+        dws = torch.empty_like(spline_w) if need_dw else None
+        dlw = torch.empty_like(lin_w) if need_dw else None
+        dlb = torch.empty(out_f, device=x.device, dtype=torch.float32) if need_dw else None
+        call('rovit_kan_layer_bwd', ptr(x), ptr(spline_w), ptr(knots), ptr(lin_w), ptr(out), ptr(g), ptr(dx), ptr(dws),
+             ptr(dlw), ptr(dlb), B, in_f, out_f, knots.numel(), ctx.act, 0, stream_ptr())
+        return dx, dws, None, dlw, dlb, None
+
+
+# ------------------------------------------------------------------------------------------------
+# The three MLP heads (reference: models/heads.py:17-22, 38-43, 91-102; gate: models/rovit_kan.py:93-116)
+# ------------------------------------------------------------------------------------------------
+class HeadsFn(torch.autograd.Function):
+    """inputs: features, stage, masks (list of 3 tensors or None), then the 14 parameters.
+    outputs: (cls_logits, ordinal_logits, mu, log_var); inactive heads give zero-size placeholders."""
+
+    @staticmethod
+    def forward(ctx, features, stage: int, masks, *params):
+        features = _f32c(features)
+        params = [_f32c(p) for p in params]
+        B, embed = features.shape
+        hid = params[0].shape[0]
+        ncls = params[2].shape[0]
+        dev = features.device
+        hidden = torch.empty(3, B, hid, device=dev, dtype=torch.float32)
+        cls = torch.empty(B, ncls, device=dev, dtype=torch.float32)
+        ordl = torch.empty(B, ncls - 1, device=dev, dtype=torch.float32) if stage >= 2 else None
+        mu = torch.empty(B, 1, device=dev, dtype=torch.float32) if stage >= 3 else None
+        lv = torch.empty(B, 1, device=dev, dtype=torch.float32) if stage >= 3 else None
+        parr = ptr_array(params)
+        marr = ptr_array([_f32c(m) if m is not None else None for m in masks]) if masks is not None else None
+        call('rovit_heads_fwd', ptr(features), parr, marr, ptr(hidden), ptr(cls), ptr(ordl), ptr(mu), ptr(lv),
+             B, embed, hid, ncls, stage, stream_ptr())
+        ctx.save_for_backward(features, hidden, lv if lv is not None else cls.new_empty(0), *params)
+        ctx.masks = masks
+        ctx.stage = stage
+        ctx.dims = (B, embed, hid, ncls)
+        empty = cls.new_empty(0)
+        outs = (cls, ordl if ordl is not None else empty, mu if mu is not None else empty, lv if lv is not None else empty)
+        ctx.mark_non_differentiable(*[o for o in outs if o.numel() == 0])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_cls, g_ord, g_mu, g_lv):
+        features, hidden, lv, *params = ctx.saved_tensors
+        B, embed, hid, ncls = ctx.dims
+        stage = ctx.stage
+        dev = features.device
+
+        def act(g, active):
+            return _f32c(g) if (active and g is not None) else None
+        g_cls = act(g_cls, True)
+        g_ord = act(g_ord, stage >= 2)
+        g_mu = act(g_mu, stage >= 3)
+        g_lv = act(g_lv, stage >= 3)
+        if (g_mu is None) != (g_lv is None):          # one of the pair unused by the loss: treat as zero
+            z = torch.zeros(B, 1, device=dev, dtype=torch.float32)
+            g_mu = g_mu if g_mu is not None else z
+            g_lv = g_lv if g_lv is not None else z
+        grads: List[Optional[torch.Tensor]] = [None] * 14
+        live = [g_cls is not None] * 4 + [g_ord is not None] * 4 + [g_mu is not None] * 6
+        for i, p in enumerate(params):
+            if live[i]:
+                grads[i] = torch.empty_like(p)
+        dfeat = torch.empty_like(features)
+        scratch = torch.empty(B, hid, device=dev, dtype=torch.float32)
+        masks = ctx.masks
+        marr = ptr_array([_f32c(m) if m is not None else None for m in masks]) if masks is not None else None
+        call('rovit_heads_bwd', ptr(features), ptr_array(params), marr, ptr(hidden), ptr(lv) if lv.numel() else None,
+             ptr(g_cls), ptr(g_ord), ptr(g_mu), ptr(g_lv), ptr(dfeat), ptr_array(grads), ptr(scratch),
+             B, embed, hid, ncls, 0, stream_ptr())
+        return (dfeat, None, None, *grads)
+
+
+class MLPHeadFn(torch.autograd.Function):
+    """One stand-alone head: Linear -> ReLU -> dropout mask -> one or more output Linears
+    (models/heads.py:17-22, 38-43, 91-102).  inputs: x, mask|None, flags-per-output, w1, b1, (w, b)*."""
+
+    @staticmethod
+    def forward(ctx, x, mask, out_flags, w1, b1, *outs):
+        x, w1, b1 = _f32c(x), _f32c(w1), _f32c(b1)
+        outs = [_f32c(t) for t in outs]
+        mask = _f32c(mask) if mask is not None else None
+        B, embed = x.shape
+        hid = w1.shape[0]
+        st = stream_ptr()
+        h = torch.empty(B, hid, device=x.device, dtype=torch.float32)
+        call('rovit_linear_fwd', ptr(x), ptr(w1), ptr(b1), ptr(mask), ptr(h), B, embed, hid, 1, st)
+        ys = []
+        for k, flags in enumerate(out_flags):
+            w, b = outs[2 * k], outs[2 * k + 1]
+            y = torch.empty(B, w.shape[0], device=x.device, dtype=torch.float32)
+            call('rovit_linear_fwd', ptr(h), ptr(w), ptr(b), None, ptr(y), B, hid, w.shape[0], flags, st)
+            ys.append(y)
+        ctx.save_for_backward(x, h, w1, *outs, *ys)
+        ctx.mask, ctx.out_flags = mask, tuple(out_flags)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        n = len(ctx.out_flags)
+        x, h, w1, *rest = ctx.saved_tensors
+        outs, ys = rest[:2 * n], rest[2 * n:]
+        B, embed = x.shape
+        hid = w1.shape[0]
+        st = stream_ptr()
+        dh = torch.zeros(B, hid, device=x.device, dtype=torch.float32)
+        grads = []
+        for k in range(n):
+            w = outs[2 * k]
+            g = gys[k]
+            if g is None:
+                grads += [None, None]
+                continue
+            g = _f32c(g)
+            dw, db = torch.empty_like(w), torch.empty(w.shape[0], device=x.device, dtype=torch.float32)
+            yc = ys[k] if (ctx.out_flags[k] & 2) else None
+            call('rovit_linear_bwd', ptr(h), ptr(w), ptr(g), ptr(yc), ptr(ctx.mask), ptr(h), ptr(dh), ptr(dw), ptr(db),
+                 B, hid, w.shape[0], 1, st)
+            grads += [dw, db]
+        dx = torch.empty_like(x)
+        dw1, db1 = torch.empty_like(w1), torch.empty(hid, device=x.device, dtype=torch.float32)
+        call('rovit_linear_bwd', ptr(x), ptr(w1), ptr(dh), None, None, None, ptr(dx), ptr(dw1), ptr(db1), B, embed, hid, 0, st)
+        return (dx, None, None, dw1, db1, *grads)
+
+
+# ------------------------------------------------------------------------------------------------
+# DeiT-Tiny backbone (reference: models/backbone.py:23-25 -> timm VisionTransformer.forward)
+# ------------------------------------------------------------------------------------------------
+class VitEngine:
+    """Owns the device buffers of one backbone instance: prepared bf16 weights, activation workspaces and the
+    flat gradient buffer.  One engine per DeiTTinyBackbone module."""
+
+    def __init__(self, depth: int):
+        self.depth = depth
+        self.n_params = native.load().rovit_vit_num_params(depth)
+        self.prep: Optional[torch.Tensor] = None
+        self._prep_key = None
+        self._ws_pool = {}          # (batch, training) -> list of free workspaces
+        self.grad_flat: Optional[torch.Tensor] = None
+        self.grad_stage: Optional[torch.Tensor] = None
+        self.grad_views: Optional[List[torch.Tensor]] = None
+        self.stage_views: Optional[List[torch.Tensor]] = None
+        # called as hook(engine, first_block, last_block) after each backward range has been enqueued
+        self.backward_ranges: Optional[Sequence] = None
+        self.range_hook = None
+
+    # -- prepared weights ---------------------------------------------------------------------
+    def prepare(self, params: Sequence[torch.Tensor]):
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if key == self._prep_key:
+            return
+        dev = params[0].device
+        lib = native.load()
+        if self.prep is None or self.prep.device != dev:
+            self.prep = torch.empty(lib.rovit_vit_prep_bytes(self.depth), dtype=torch.uint8, device=dev)
+        call('rovit_vit_prepare', ptr_array(params), ptr(self.prep), self.depth, stream_ptr())
+        self._prep_key = key
+
+    # -- workspaces ---------------------------------------------------------------------------
+    def take_ws(self, batch: int, training: bool, dev) -> torch.Tensor:
+        pool = self._ws_pool.setdefault((batch, training, str(dev)), [])
+        if pool:
+            return pool.pop()
+        nbytes = native.load().rovit_vit_workspace_bytes(batch, self.depth, int(training))
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+    def give_ws(self, batch: int, training: bool, ws: torch.Tensor):
+        pool = self._ws_pool.setdefault((batch, training, str(ws.device)), [])
+        if len(pool) < 2:
+            pool.append(ws)
+
+    # -- flat gradients -----------------------------------------------------------------------
+    def ensure_grads(self, params: Sequence[torch.Tensor]):
+        dev = params[0].device
+        total = sum(p.numel() for p in params)
+        if self.grad_flat is None or self.grad_flat.device != dev or self.grad_flat.numel() != total:
+            self.grad_flat = torch.zeros(total, dtype=torch.float32, device=dev)
+            self.grad_stage = torch.empty(total, dtype=torch.float32, device=dev)
+            self.grad_views, self.stage_views = [], []
+            off = 0
+            for p in params:
+                n = p.numel()
+                self.grad_views.append(self.grad_flat[off:off + n].view_as(p))
+                self.stage_views.append(self.grad_stage[off:off + n].view_as(p))
+                off += n
+
+
+class VitFn(torch.autograd.Function):
+    """features = backbone(images).  Parameter gradients are written by the HIP backward into the engine's
+    flat buffer and installed as ``param.grad`` directly (autograd's per-tensor accumulation would cost ~150
+    tiny copy kernels); accumulation semantics are preserved (grad += new when a grad already exists)."""
+
+    @staticmethod
+    def forward(ctx, images, engine: VitEngine, training: bool, *params):
+        images = _f32c(images)
+        if images.dim() != 4 or tuple(images.shape[1:]) != (3, 224, 224):
+            raise native.RovitHipError(f'backbone expects (B,3,224,224) images, got {tuple(images.shape)}')
+        B = images.shape[0]
+        dev = images.device
+        engine.prepare(params)
+        need_bwd = training and any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        # (inside Function.forward grad mode is disabled; the caller passes the real flag via `training`)
+        need_bwd = training and any(p.requires_grad for p in params)
+        ws = engine.take_ws(B, need_bwd, dev)
+        feats = torch.empty(B, 192, device=dev, dtype=torch.float32)
+        parr = ptr_array(params)
+        call('rovit_vit_forward', ptr(images), parr, ptr(engine.prep), ptr(ws), ptr(feats), B, engine.depth,
+             int(need_bwd), stream_ptr())
+        ctx.engine, ctx.batch, ctx.need_bwd = engine, B, need_bwd
+        if need_bwd:
+            ctx.ws = ws
+            ctx.params = params
+        else:
+            engine.give_ws(B, need_bwd, ws)
+        return feats
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        if not ctx.need_bwd:
+            return (None,) * (3 + ctx.engine.n_params)
+        engine: VitEngine = ctx.engine
+        params = ctx.params
+        dfeat = _f32c(dfeat)
+        engine.ensure_grads(params)
+        fresh = all(p.grad is None for p in params)
+        owned = (not fresh) and all(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+                                    for p, v in zip(params, engine.grad_views))
+        # fresh: write straight into the flat buffer; owned: stage + one fused add; else: per-tensor fallback
+        targets = engine.grad_views if fresh else engine.stage_views
+        parr, garr = ptr_array(params), ptr_array(targets)
+        depth = engine.depth
+        ranges = engine.backward_ranges or [(depth - 1, 0)]
+        for first, last in ranges:
+            call('rovit_vit_backward', ptr(dfeat), parr, ptr(engine.prep), ptr(ctx.ws), garr, ctx.batch, depth,
+                 first, last, stream_ptr())
+            if engine.range_hook is not None and fresh:
+                engine.range_hook(engine, first, last)
+        if fresh:
+            for p, v in zip(params, engine.grad_views):
+                if p.requires_grad:
+                    p.grad = v
+        elif owned:
+            engine.grad_flat.add_(engine.grad_stage)
+        else:
+            for p, v in zip(params, engine.stage_views):
+                if p.requires_grad:
+                    p.grad = v.clone() if p.grad is None else p.grad.add_(v)
+        engine.give_ws(ctx.batch, True, ctx.ws)
+        ctx.ws = None
+        return (None,) * (3 + engine.n_params)

@@ -1,0 +1,107 @@
+"""ctypes binding of librovit_hip.so (C ABI declared in include/rovit_hip.h).
+
+No libtorch linkage: tensors cross the boundary as raw device pointers plus the caller's current HIP stream.
+There is NO fallback: if the shared library is missing, or a tensor is not on a CUDA/HIP device, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, 'lib', 'librovit_hip.so')
+
+_lib: Optional[C.CDLL] = None
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/rovit_hip.h one to one
+SIGNATURES = {
+    'rovit_version': (_i, []),
+    'rovit_last_error_string': (C.c_char_p, []),
+    'rovit_kan_basis': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    'rovit_kan_layer_fwd': (_i, [_vp] * 6 + [_i] * 5 + [_vp]),
+    'rovit_kan_layer_bwd': (_i, [_vp] * 10 + [_i] * 6 + [_vp]),
+    'rovit_linear_fwd': (_i, [_vp] * 5 + [_i] * 4 + [_vp]),
+    'rovit_linear_bwd': (_i, [_vp] * 9 + [_i] * 4 + [_vp]),
+    'rovit_heads_fwd': (_i, [_vp] * 8 + [_i] * 5 + [_vp]),
+    'rovit_heads_bwd': (_i, [_vp] * 12 + [_i] * 5 + [_vp]),
+    'rovit_vit_num_params': (_i, [_i]),
+    'rovit_vit_prep_bytes': (_sz, [_i]),
+    'rovit_vit_workspace_bytes': (_sz, [_i, _i, _i]),
+    'rovit_vit_prepare': (_i, [_vp, _vp, _i, _vp]),
+    'rovit_vit_forward': (_i, [_vp] * 5 + [_i] * 3 + [_vp]),
+    'rovit_vit_backward': (_i, [_vp] * 5 + [_i] * 4 + [_vp]),
+    'rovit_gemm_nt': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    'rovit_set_gemm_tile': (_i, [_i]),
+    'rovit_wgrad_splits': (_i, [_i, _i, _i]),
+    'rovit_wgrad_workspace_bytes': (_sz, [_i, _i, _i]),
+    'rovit_wgrad': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'rovit_wgrad_reduce': (_i, [_vp, _i, _i, _i] + [_vp] * 8 + [_vp]),
+    'rovit_attention_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    'rovit_attention_bwd': (_i, [_vp] * 5 + [_i] * 4 + [_f, _vp]),
+    'rovit_layernorm_fwd': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
+    'rovit_layernorm_bwd': (_i, [_vp] * 5 + [_i, _i, _vp]),
+    'rovit_im2col': (_i, [_vp, _vp, _i, _vp]),
+    'rovit_cls_rows': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    'rovit_cls_norm_fwd': (_i, [_vp] * 6 + [_i, _i, _f, _vp]),
+    'rovit_cls_norm_bwd': (_i, [_vp] * 8 + [_i, _i, _vp]),
+    'rovit_pos_grad': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    'rovit_prep_weight': (_i, [_vp] * 7 + [_i, _i, _vp]),
+}
+
+
+class RovitHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises if it has not been built -- there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RovitHipError(
+                f'{LIB_PATH} not found: build it with `python __graft_entry__.py` (or `make -C csrc`). '
+                'The RoViT-KAN HIP path has no CPU fallback.')
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().rovit_last_error_string()
+        raise RovitHipError(f'{what} failed (code {rc}): {msg.decode() if msg else ""}')
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RovitHipError('RoViT-KAN HIP kernels need tensors on a CUDA/HIP device (got a CPU tensor); '
+                            'there is no CPU fallback in the product path')
+    if not t.is_contiguous():
+        raise RovitHipError('non-contiguous tensor passed to a HIP kernel')
+    return t.data_ptr()
+
+
+def ptr_array(tensors: Sequence[Optional[torch.Tensor]]):
+    """HOST array of device pointers (kept alive by the caller for the duration of the call)."""
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = ptr(t)
+    return arr
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args), name)

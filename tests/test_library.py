@@ -1,0 +1,98 @@
+"""CPU tests of the boundary: the C-ABI library builds/loads and exports every symbol include/rovit_hip.h
+declares; host-side logic that needs no GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'rovit_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(rovit_[a-z0-9_]+)\s*\(', txt)))
+
+
+@pytest.fixture(scope='module')
+def native():
+    from rovit_hip import native as n
+    if not os.path.exists(n.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return n
+
+
+def test_library_exports_every_declared_symbol(native):
+    lib = ctypes.CDLL(native.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), f'{s} declared in include/rovit_hip.h but not exported'
+    assert set(native.SIGNATURES) == set(syms)
+    lib.rovit_version.restype = ctypes.c_int
+    assert lib.rovit_version() >= 100
+
+
+def test_host_side_size_queries(native):
+    lib = native.load()
+    assert lib.rovit_vit_num_params(12) == 6 + 12 * 12
+    assert lib.rovit_vit_prep_bytes(12) > 12 * 2 * (3 * 192 * 192 + 192 * 192 + 2 * 768 * 192) * 2
+    infer = lib.rovit_vit_workspace_bytes(256, 12, 0)
+    train = lib.rovit_vit_workspace_bytes(256, 12, 1)
+    assert train > infer > 256 * 197 * 192 * 4
+    assert lib.rovit_wgrad_splits(50432, 768, 192) % 8 == 0
+
+
+def test_product_path_has_no_cpu_fallback(native):
+    from rovit_hip import RovitHipError
+    from models.kan import KANLayer, KANSeverityModule
+    from models.rovit_kan import RoViTKAN
+    with pytest.raises(RovitHipError):
+        KANLayer(8, 4)(torch.randn(2, 8))
+    with pytest.raises(RovitHipError):
+        KANSeverityModule([8, 4, 1])(torch.randn(2, 8))
+    m = RoViTKAN(pretrained=False)
+    with pytest.raises(RovitHipError):
+        m(torch.randn(1, 3, 224, 224))
+
+
+def test_module_surface_matches_reference_contract(native):
+    """constructor spellings, attributes and state_dict keys the reference's callers touch."""
+    from oracle import ref_cpu
+    from models import RoViTKAN, DeiTTinyBackbone, KANSeverityModule, KANLayer, BSplineBasis, freeze_backbone  # noqa: F401
+    m = RoViTKAN(pretrained=False)
+    sd = ref_cpu.init_rovit_state(seed=0)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in sd.items()}
+    assert m.count_parameters() == {'backbone': 5524416, 'classification_head': 25220, 'ordinal_head': 25091,
+                                    'uncertainty_head': 24962, 'kan_module': 106705, 'total': 5706394}
+    assert m.backbone.embed_dim == 192 and m.backbone.model.num_features == 192
+    assert hasattr(m.backbone.model.blocks[0].attn, 'attn_drop') and hasattr(m.backbone.model.blocks[-1], 'norm1')
+    assert m.kan_module.kan_layers[0].in_features == 192 and m.kan_module.kan_layers[0].knots.numel() == 11
+    assert torch.equal(m.kan_module.kan_layers[0].knots, ref_cpu.make_knots(5, 3))
+    m.curriculum_stage = 2
+    assert m.curriculum_stage == 2
+    with pytest.raises(AssertionError):
+        m.curriculum_stage = 0
+    m.freeze_backbone()
+    assert m.count_parameters()['backbone'] == 0 and m.count_parameters()['total'] == 181978
+    m.unfreeze_backbone()
+    freeze_backbone(m, True)
+    with pytest.raises(AttributeError):
+        freeze_backbone(torch.nn.Linear(2, 2))
+    # the spelling scripts/train.py:88-97 and evaluation/evaluator.py:233-242 use
+    m2 = RoViTKAN(embed_dim=192, hidden_dim=128, num_classes=4, kan_layers=[192, 64, 16, 1], kan_num_knots=5,
+                  kan_degree=3, dropout=0.3, pretrained=False)
+    assert m2.count_parameters()['total'] == 5706394
+
+    class Cfg:          # config-object spelling (experiments/ablation.py:264)
+        class model:
+            embed_dim, hidden_dim, kan_layers, kan_num_knots, kan_degree, dropout, pretrained = 192, 128, [192, 64, 16, 1], 5, 3, 0.3, False
+
+        class data:
+            num_classes = 4
+    assert RoViTKAN(Cfg).count_parameters()['total'] == 5706394
+    assert len([n for n, _ in m.named_parameters() if 'backbone' in n]) == 6 + 12 * 12

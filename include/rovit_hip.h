@@ -106,6 +106,7 @@ int rovit_vit_backward(const float* d_features, const float* const* params, cons
 int rovit_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, int epi, void* out,
                   int ldo, void* out2, float* xres, int ldx, const void* mul, int ldm, const float* pos, int tokens,
                   rovit_stream_t stream);
+int rovit_set_gemm_debug(int flags); /* developer knob: bit 0 skips the epilogue stores (timing experiments) */
 int rovit_set_gemm_tile(int tile); /* tuning knob: 0 = 128x192 tiles where N allows, 1 = 128x96 */
 /* G(N,K) = dY(M,N)^T A(M,K) and colsum(dY), split over M into `splits` fp32 slabs inside ws */
 int rovit_wgrad_splits(int M, int N, int K);

@@ -356,7 +356,7 @@ def focal_loss(logits, targets, gamma=2.0, alpha=None):
 
 def ordinal_bce_loss(cum_logits, targets):
     """training/losses.py:48-72: BCE-with-logits on (targets > k), mean over thresholds then batch."""
-    k = torch.arange(cum_logits.shape[1])
+    k = torch.arange(cum_logits.shape[1], device=cum_logits.device)
     bt = (targets.unsqueeze(1) > k).float()
     return F.binary_cross_entropy_with_logits(cum_logits, bt, reduction='none').mean(dim=1).mean()
 
@@ -378,7 +378,7 @@ def joint_loss(out, class_targets, severity_targets, stage=4, lambda_ord=1.0, mu
     """training/losses.py:139-181 (stage-gated weighted sum)."""
     losses = {'cls_loss': focal_loss(out['cls_logits'], class_targets, gamma, alpha)}
     total = losses['cls_loss']
-    zero = torch.tensor(0.0)
+    zero = torch.zeros((), device=total.device)
     losses['ord_loss'] = losses['unc_loss'] = losses['kan_loss'] = zero
     if stage >= 2 and out['ordinal_logits'] is not None:
         losses['ord_loss'] = ordinal_bce_loss(out['ordinal_logits'], severity_targets)

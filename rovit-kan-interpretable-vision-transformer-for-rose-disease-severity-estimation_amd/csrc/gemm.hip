@@ -31,9 +31,25 @@ struct GemmArgs {
   const bf16* mul; int ldm;
   const float* pos; int tokens;
   int n_tiles;
+  int dbg;            // developer knob (bit 0: skip epilogue stores, bit 1: skip MFMAs)
 };
 
-__device__ __forceinline__ float gelu_cdf(float x) { return 0.5f * (1.f + erff(x * 0.70710678118654752f)); }
+// GELU (exact-erf form) and its derivative from ONE exponential: with z = |x|/sqrt(2), e = exp(-z^2) = exp(-x^2/2),
+// erf(z) = 1 - (a1 t + ... + a5 t^5) e, t = 1/(1 + p z)   (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7),
+// Phi(x) = 0.5 (1 + sign(x) erf(z)),  gelu = x Phi,  gelu' = Phi + x e / sqrt(2 pi).
+__device__ __forceinline__ void gelu_and_grad(float x, float& act, float& dact) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float e = __expf(-z * z);
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float erfz = fmaf(-p * t, e, 1.f);
+  const float cdf = 0.5f * (1.f + copysignf(erfz, x));
+  act = x * cdf;
+  dact = fmaf(x * 0.3989422804014327f, e, cdf);
+}
 
 template <int EPI>
 __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, f32x4 v) {
@@ -47,10 +63,9 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, f32x4
     f32x4 a, d;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float x = v[r];
-      const float cdf = gelu_cdf(x);
-      a[r] = x * cdf;                                                      // exact-erf GELU (timm default)
-      d[r] = cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);        // d gelu / dx
+      float ga, gd;
+      gelu_and_grad(v[r], ga, gd);                                         // exact-erf GELU (timm default)
+      a[r] = ga; d[r] = gd;
     }
     *(bf16x4*)(g.out + (size_t)m * g.ldo + n) = pack4(a);
     if (g.out2) *(bf16x4*)(g.out2 + (size_t)m * g.ldo + n) = pack4(d);
@@ -173,6 +188,227 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmArgs g)
       for (int j = 0; j < TN; ++j) epilogue4<EPI>(g, m, n0 + wn * WTN + j * 16 + lg * 4, acc[i][j]);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Weight-stationary persistent GEMM for the shapes this model actually has (N a multiple of 192, K in
+// {192, 576, 768}).  A workgroup owns one 192-column chunk of W: wave (wn, wk) keeps W[48 wn .. +48][its K slice]
+// as MFMA fragments in REGISTERS for its whole life and walks a contiguous range of BM-row tiles of A.  Only A
+// goes through LDS (double-buffered, next tile's global loads in flight during the current tile's MFMAs), so
+// LDS traffic is one fragment read per 3 MFMAs and there is one barrier per tile, not per K step.
+// WK == 2 splits K over two waves per column slice; the pair exchanges partial accumulators through LDS and
+// each finishes half of the tile's rows.
+// ------------------------------------------------------------------------------------------------------
+template <int KS, int WK, int BM, int EPI>
+__global__ __launch_bounds__(256 * WK) void gemm_ws_kernel(const GemmArgs g, int tiles_per_wg, int n_tiles_m) {
+  constexpr int K = KS * 32 * WK;
+  constexpr int NT = 256 * WK;
+  constexpr int STR = K + 16;                  // LDS row stride: conflict-free ds_read_b128 for K = 192/576/768
+  constexpr int TM = BM / 16;
+  constexpr int CPR = K / 8;
+  constexpr int NCH = BM * CPR;
+  constexpr int CH = (NCH + NT - 1) / NT;
+  constexpr int TOWN = TM / WK;                // row tiles each wave finishes
+  extern __shared__ __attribute__((aligned(16))) bf16 lds[];
+  bf16* As = lds;                              // [2][BM][STR]
+  f32x4* xch = (f32x4*)(lds + 2 * BM * STR);   // WK==2: [2][8 waves][TOWN*3][64]
+  constexpr int CSTR = 192 + 8;                // staged output tile [BM][CSTR] bf16
+  bf16* Cs = lds + 2 * BM * STR + (WK == 2 ? 2 * 8 * TOWN * 3 * 64 * 8 : 0);
+
+  // ids that share an XCD get the same row range and different column chunks
+  const int nchunks = g.n_tiles;
+  const int bid = blockIdx.x;
+  const int chunk = (bid >> 3) % nchunks;
+  const int p = (bid / (8 * nchunks)) * 8 + (bid & 7);
+  const int tile0 = p * tiles_per_wg;
+  int ntile = n_tiles_m - tile0;
+  ntile = ntile > tiles_per_wg ? tiles_per_wg : ntile;
+  if (ntile <= 0) return;
+  const int n0 = chunk * 192;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 3, wk = wave >> 2;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  // stationary W fragments: rows (output columns) n0 + 48 wn + 16 j + l15, k = wk*KS*32 + 32 ks + 8 lg
+  bf16x8 wf[3][KS];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      wf[j][ks] = *(const bf16x8*)(g.W + (size_t)(n0 + 48 * wn + 16 * j + l15) * g.ldw + wk * KS * 32 + ks * 32 + lg * 8);
+
+  int c_row[CH], c_col[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = tid + i * NT;
+    c_row[i] = c / CPR; c_col[i] = (c - c_row[i] * CPR) * 8;
+  }
+  bf16x8 rv[CH];
+  auto gload = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      if (NCH % NT == 0 || tid + i * NT < NCH) {
+        int gr = tile * BM + c_row[i];
+        gr = gr < g.M ? gr : g.M - 1;
+        rv[i] = *(const bf16x8*)(g.A + (size_t)gr * g.lda + c_col[i]);
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+      if (NCH % NT == 0 || tid + i * NT < NCH) *(bf16x8*)(As + (buf * BM + c_row[i]) * STR + c_col[i]) = rv[i];
+  };
+
+  gload(tile0);
+  lstore(0);
+  if (ntile > 1) gload(tile0 + 1);
+  __syncthreads();
+
+  for (int t = 0; t < ntile; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntile) lstore(cur ^ 1);           // tile t+1 (loaded during tile t-1's compute) -> other buffer
+    if (t + 2 < ntile) gload(tile0 + t + 2);      // in flight during this tile's MFMAs
+    f32x4 acc[TM][3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16* Ac = As + (cur * BM + l15) * STR + wk * KS * 32 + lg * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 af[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(Ac + i * 16 * STR + ks * 32);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(wf[j][ks], af[i], acc[i][j]);     // D[n][m]
+    }
+    const int mbase = (g.dbg & 1) ? g.M : (tile0 + t) * BM;
+    constexpr bool STAGED = (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_MUL);
+    if (WK == 2) {
+      // partner = same wn, other wk.  Wave wk finishes row tiles i with (i % WK) == wk; it ships the others.
+      f32x4* xo = xch + ((size_t)(cur * 8 + (wave ^ 4)) * TOWN * 3) * 64 + lane;    // partner's inbox
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if ((i % WK) != wk) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) xo[((i / WK) * 3 + j) * 64] = acc[i][j];
+        }
+      }
+      __syncthreads();
+      const f32x4* xi = xch + ((size_t)(cur * 8 + wave) * TOWN * 3) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if ((i % WK) == wk) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const f32x4 o = xi[((i / WK) * 3 + j) * 64];
+            acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
+          }
+        }
+      }
+    }
+    if (!STAGED) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if ((i % WK) == wk) {
+          const int m = mbase + i * 16 + l15;
+          if (m < g.M) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) epilogue4<EPI>(g, m, n0 + 48 * wn + 16 * j + 4 * lg, acc[i][j]);
+          }
+        }
+      }
+      if (WK == 1) __syncthreads();
+    } else {
+      // bf16 outputs: stage the (acc + bias) tile in LDS, then write whole 384-byte rows with 16-byte lanes
+      // (the accumulator layout alone would give 16 rows x 32 bytes per store instruction).
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if ((i % WK) == wk) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            f32x4 v = acc[i][j];
+            const int nl = 48 * wn + 16 * j + 4 * lg;
+            if (g.bias) {
+              const float4 bb = *(const float4*)(g.bias + n0 + nl);
+              v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            }
+            *(bf16x4*)(Cs + (i * 16 + l15) * CSTR + nl) = pack4(v);
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < (BM * 24 + NT - 1) / NT; ++q) {
+        const int c = tid + q * NT;
+        const int row = c / 24, ch = c - row * 24;
+        const int m = mbase + row;
+        if (((BM * 24) % NT == 0 || c < BM * 24) && m < g.M) {
+          const bf16x8 pv = *(const bf16x8*)(Cs + row * CSTR + ch * 8);
+          const size_t o = (size_t)m * g.ldo + n0 + ch * 8;
+          if (EPI == EPI_BF16) {
+            *(bf16x8*)(g.out + o) = pv;
+          } else if (EPI == EPI_GELU) {
+            bf16x8 av, dv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float ga, gd;
+              gelu_and_grad((float)pv[e], ga, gd);
+              av[e] = (bf16)ga; dv[e] = (bf16)gd;
+            }
+            *(bf16x8*)(g.out + o) = av;
+            if (g.out2) *(bf16x8*)(g.out2 + o) = dv;
+          } else {   // EPI_MUL
+            const bf16x8 mv = *(const bf16x8*)(g.mul + (size_t)m * g.ldm + n0 + ch * 8);
+            bf16x8 rv2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rv2[e] = (bf16)((float)pv[e] * (float)mv[e]);
+            *(bf16x8*)(g.out + o) = rv2;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int KS, int WK, int BM>
+int launch_ws(const GemmArgs& g0, int epi, hipStream_t st) {
+  GemmArgs g = g0;
+  g.n_tiles = g.N / 192;                                   // column chunks
+  const int tiles_m = (g.M + BM - 1) / BM;
+  const int wg_per_cu = WK == 1 ? 2 : 1;
+  int pmax = (256 * wg_per_cu) / g.n_tiles;
+  pmax = pmax < 8 ? 8 : pmax / 8 * 8;
+  int tpw = (tiles_m + pmax - 1) / pmax;                   // tiles per workgroup
+  int P = (tiles_m + tpw - 1) / tpw;
+  P = (P + 7) / 8 * 8;                                     // whole groups of 8 ids (one per XCD)
+  constexpr int K = KS * 32 * WK;
+  const size_t lds = (size_t)2 * BM * (K + 16) * sizeof(bf16) + (WK == 2 ? (size_t)2 * 8 * (BM / 16 / WK) * 3 * 64 * sizeof(f32x4) : 0) +
+                     (size_t)BM * (192 + 8) * sizeof(bf16);
+  dim3 grid(P * g.n_tiles), block(256 * WK);
+#define LAUNCHW(E)                                                                                        \
+  case E: {                                                                                               \
+    static bool attr_set = false;                                                                         \
+    if (!attr_set) {                                                                                      \
+      (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<KS, WK, BM, E>,                               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+      attr_set = true;                                                                                    \
+    }                                                                                                     \
+    hipLaunchKernelGGL((gemm_ws_kernel<KS, WK, BM, E>), grid, block, lds, st, g, tpw, tiles_m);           \
+    break;                                                                                                \
+  }
+  switch (epi) {
+    LAUNCHW(EPI_BF16) LAUNCHW(EPI_GELU) LAUNCHW(EPI_RESID) LAUNCHW(EPI_MUL) LAUNCHW(EPI_PATCH)
+    default: rovit_set_error("gemm_ws: unknown epilogue %d", epi); return ROVIT_ERR_SHAPE;
+  }
+#undef LAUNCHW
+  ROVIT_CHECK_LAUNCH("gemm_ws_kernel");
+  return ROVIT_OK;
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -339,45 +575,64 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            int splits, int N, int K, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ dW,
                                                            float* __restrict__ db, float* __restrict__ Gout) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  const int total = N * K;
-  if (e < total) {
-    float s = 0.f;
-    for (int i = 0; i < splits; ++i) s += slab[(size_t)i * total + e];
+  const int q = blockIdx.x * 256 + threadIdx.x;      // one float4 (4 consecutive k of one row n) per thread
+  const int total4 = N * K / 4;
+  if (q < total4) {
+    const float4* sp = (const float4*)slab + q;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int i = 0; i < splits; ++i) {
+      const float4 v = sp[(size_t)i * total4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
     if (gamma) {
-      const int n = e / K, k = e - n * K;
+      const int e = q * 4, n = e / K, k = e - n * K;
       float cb = 0.f;
       for (int i = 0; i < splits; ++i) cb += colsum[(size_t)i * N + n];
-      Gout[e] = s;
-      dW[e] = gamma[k] * s + beta[k] * cb;
+      ((float4*)Gout)[q] = s;
+      const float4 g = *(const float4*)(gamma + k), bt = *(const float4*)(beta + k);
+      ((float4*)dW)[q] = make_float4(g.x * s.x + bt.x * cb, g.y * s.y + bt.y * cb, g.z * s.z + bt.z * cb, g.w * s.w + bt.w * cb);
     } else {
-      dW[e] = s;
+      ((float4*)dW)[q] = s;
     }
   }
-  if (e < N) {
+  if (q < N) {
     float cb = 0.f;
-    for (int i = 0; i < splits; ++i) cb += colsum[(size_t)i * N + e];
-    db[e] = cb;
+    for (int i = 0; i < splits; ++i) cb += colsum[(size_t)i * N + q];
+    db[q] = cb;
   }
 }
 
+// dgamma[k] = sum_n W[n][k] G[n][k];  dbeta[k] = sum_n W[n][k] db[n].  One workgroup = 32 columns x 8 row groups.
 __global__ __launch_bounds__(256) void wgrad_affine_kernel(const float* __restrict__ G, const float* __restrict__ W,
                                                            const float* __restrict__ db, int N, int K,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= K) return;
+  __shared__ float s_g[8][32], s_b[8][32];
+  const int kc = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + kc;
   float sg = 0.f, sb = 0.f;
-  for (int n = 0; n < N; ++n) {
-    const float w = W[(size_t)n * K + k];
-    sg = fmaf(w, G[(size_t)n * K + k], sg);
-    sb = fmaf(w, db[n], sb);
+  if (k < K) {
+#pragma unroll 4
+    for (int n = grp; n < N; n += 8) {
+      const float w = W[(size_t)n * K + k];
+      sg = fmaf(w, G[(size_t)n * K + k], sg);
+      sb = fmaf(w, db[n], sb);
+    }
   }
-  dgamma[k] = sg; dbeta[k] = sb;
+  s_g[grp][kc] = sg; s_b[grp][kc] = sb;
+  __syncthreads();
+  if (grp == 0 && k < K) {
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { sg += s_g[i][kc]; sb += s_b[i][kc]; }
+    dgamma[k] = sg; dbeta[k] = sb;
+  }
 }
 
 }  // namespace
 
-static int g_gemm_tile = 0;      // 0: 128x192 tiles, 1: 128x96 tiles
+static int g_gemm_dbg = 0;
+extern "C" int rovit_set_gemm_debug(int d) { g_gemm_dbg = d; return ROVIT_OK; }
+static int g_gemm_tile = 0;      // 0: weight-stationary kernel where it applies, 2: tiled 128x192, 3: tiled 128x96
 extern "C" int rovit_set_gemm_tile(int t) { g_gemm_tile = t; return ROVIT_OK; }
 
 extern "C" int rovit_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, int epi,
@@ -391,7 +646,7 @@ extern "C" int rovit_gemm_nt(const void* A, int lda, const void* W, int ldw, int
   GemmArgs g{};
   g.A = (const bf16*)A; g.lda = lda; g.W = (const bf16*)W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias;
   g.out = (bf16*)out; g.ldo = ldo; g.out2 = (bf16*)out2; g.xres = xres; g.ldx = ldx; g.mul = (const bf16*)mul; g.ldm = ldm;
-  g.pos = pos; g.tokens = tokens;
+  g.pos = pos; g.tokens = tokens; g.dbg = g_gemm_dbg;
   switch (epi) {
     case EPI_BF16: case EPI_GELU: ROVIT_CHECK_ARG(out && ldo % 4 == 0, ROVIT_ERR_NULL, "gemm_nt: bf16 output missing"); break;
     case EPI_RESID: ROVIT_CHECK_ARG(xres && ldx % 4 == 0, ROVIT_ERR_NULL, "gemm_nt: residual stream missing"); break;
@@ -399,7 +654,12 @@ extern "C" int rovit_gemm_nt(const void* A, int lda, const void* W, int ldw, int
     case EPI_PATCH: ROVIT_CHECK_ARG(xres && pos && tokens > 1 && M % (tokens - 1) == 0, ROVIT_ERR_SHAPE, "gemm_nt: bad patch epilogue"); break;
     default: ROVIT_CHECK_ARG(false, ROVIT_ERR_SHAPE, "gemm_nt: unknown epilogue %d", epi);
   }
-  if (g_gemm_tile == 0 && N % 192 == 0) return launch_nt<128, 192, 2, 2>(g, epi, (hipStream_t)stream);
+  if (g_gemm_tile == 0 && N % 192 == 0) {
+    if (K == 192) return launch_ws<6, 1, 64>(g, epi, (hipStream_t)stream);
+    if (K == 576) return launch_ws<9, 2, 32>(g, epi, (hipStream_t)stream);
+    if (K == 768) return launch_ws<12, 2, 32>(g, epi, (hipStream_t)stream);
+  }
+  if (g_gemm_tile <= 2 && N % 192 == 0) return launch_nt<128, 192, 2, 2>(g, epi, (hipStream_t)stream);
   return launch_nt<128, 96, 2, 2>(g, epi, (hipStream_t)stream);
 }
 
@@ -409,7 +669,7 @@ extern "C" size_t rovit_wgrad_workspace_bytes(int N, int K, int splits) {
 
 extern "C" int rovit_wgrad_splits(int M, int N, int K) {
   const int tiles = (N / WG_T) * (K / WG_T);
-  int s = (512 + tiles - 1) / tiles;               // ~2 workgroups per CU
+  int s = (256 + tiles - 1) / tiles;               // ~1 workgroup per CU (slab traffic grows with the split count)
   s = (s + 7) / 8 * 8;
   const int max_s = (M + WG_MSTEP - 1) / WG_MSTEP;
   if (s > max_s) s = max_s;
@@ -444,11 +704,12 @@ extern "C" int rovit_wgrad_reduce(const float* ws, int splits, int N, int K, con
   const float* colsum = ws + (size_t)splits * N * K;
   if (gamma) ROVIT_CHECK_ARG(beta && W && dgamma && dbeta && g_scratch, ROVIT_ERR_NULL, "wgrad_reduce: affine un-fold needs beta/W/outputs");
   const int total = N * K;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, slab, colsum, splits,
+  const int nthreads = total / 4 > N ? total / 4 : N;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, (hipStream_t)stream, slab, colsum, splits,
                      N, K, gamma, beta, dW, db, g_scratch);
   ROVIT_CHECK_LAUNCH("wgrad_reduce_kernel");
   if (gamma) {
-    hipLaunchKernelGGL(wgrad_affine_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_scratch, W, db, N, K,
+    hipLaunchKernelGGL(wgrad_affine_kernel, dim3((K + 31) / 32), dim3(256), 0, (hipStream_t)stream, g_scratch, W, db, N, K,
                        dgamma, dbeta);
     ROVIT_CHECK_LAUNCH("wgrad_affine_kernel");
   }

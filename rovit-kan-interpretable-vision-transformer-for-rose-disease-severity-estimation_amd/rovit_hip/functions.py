@@ -289,7 +289,12 @@ class VitFn(torch.autograd.Function):
                     p.grad = v
         elif owned:
             engine.grad_flat.add_(engine.grad_stage)
+            if engine.range_hook is not None:          # accumulated gradients: one bucket over everything
+                engine.range_hook(engine, depth - 1, 0)
         else:
+            if engine.range_hook is not None:
+                raise native.RovitHipError('data-parallel sync needs engine-owned gradients: do not replace '
+                                           'backbone .grad tensors between backward passes')
             for p, v in zip(params, engine.stage_views):
                 if p.requires_grad:
                     p.grad = v.clone() if p.grad is None else p.grad.add_(v)

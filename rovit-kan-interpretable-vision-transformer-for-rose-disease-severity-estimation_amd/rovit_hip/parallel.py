@@ -1,0 +1,120 @@
+"""Data-parallel gradient synchronisation: one process per GPU, RCCL (torch.distributed backend "nccl") over xGMI.
+
+The reference is single-process (no collectives anywhere), so this is new work: samples are
+independent (LayerNorm only), every rank holds a full replica, and the only exchange is one averaged all-reduce of
+the gradients per step.  The backbone's gradients live in ONE flat fp32 buffer (VitEngine.grad_flat) written by the
+HIP backward block range by block range; each finished range is all-reduced on a side stream while the next range's
+kernels run (bucketed overlap, 3-4 buckets of ~5-7 MB: large enough for xGMI's per-link bandwidth, small enough
+that the last bucket's exposed tail is short).  Head/KAN gradients (0.7 MB) go in one flat bucket after backward.
+
+The class only needs ``flat`` tensors and ranges, so its bucket logic is exercised on CPU with the gloo backend.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def block_ranges(depth: int, buckets: int) -> List[Tuple[int, int]]:
+    """Split blocks depth-1..0 into `buckets` contiguous ranges in backward order, e.g. 12,3 -> (11,8),(7,4),(3,0)."""
+    buckets = max(1, min(buckets, depth))
+    edges = [round(i * depth / buckets) for i in range(buckets + 1)]
+    return [(depth - 1 - edges[i], depth - edges[i + 1]) for i in range(buckets)]
+
+
+class FlatBucketAllReduce:
+    """Averaging all-reduce of slices of one flat gradient buffer, issued on a side stream as slices become ready."""
+
+    def __init__(self, group=None, use_side_stream: bool = True):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.use_side_stream = use_side_stream
+        self._stream: Optional[torch.cuda.Stream] = None
+        self._pending = []
+        self.issued: List[Tuple[int, int]] = []          # (offset, numel) log, for tests
+
+    def _avg(self, t: torch.Tensor):
+        if self.world == 1:
+            return None
+        backend = dist.get_backend(self.group)
+        if backend == 'nccl':
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        w.wait()
+        t.div_(self.world)
+        return None
+
+    def reduce_slice(self, flat: torch.Tensor, offset: int, numel: int):
+        self.issued.append((offset, numel))
+        if self.world == 1 or numel == 0:
+            return
+        piece = flat[offset:offset + numel]
+        if flat.is_cuda and self.use_side_stream:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=flat.device)
+            self._stream.wait_stream(torch.cuda.current_stream(flat.device))     # slice is final on the main stream
+            with torch.cuda.stream(self._stream):
+                w = self._avg(piece)
+            if w is not None:
+                self._pending.append(w)
+        else:
+            w = self._avg(piece)
+            if w is not None:
+                w.wait()
+
+    def finish(self, device=None):
+        """Make the main stream wait for every issued reduction (no host sync)."""
+        for w in self._pending:
+            w.wait()                                   # stream-level wait for NCCL work objects
+        self._pending.clear()
+        if self._stream is not None:
+            torch.cuda.current_stream(device).wait_stream(self._stream)
+
+
+class GradSync:
+    """Wires FlatBucketAllReduce into a RoViTKAN model: backbone buckets overlap with backward, heads/KAN after."""
+
+    def __init__(self, model, buckets: int = 3, group=None):
+        self.model = model
+        self.engine = model.backbone.model.engine
+        self.depth = model.backbone.model.depth
+        self.reducer = FlatBucketAllReduce(group)
+        self.world = self.reducer.world
+        self.ranges = block_ranges(self.depth, buckets)
+        params = model.backbone.model.ordered_parameters()
+        sizes = [p.numel() for p in params]
+        self.prefix = sum(sizes[:6])
+        self.block_numel = sum(sizes[6:18])
+        self.other_params = [p for n, p in model.named_parameters() if not n.startswith('backbone.')]
+        if self.world > 1:
+            self.engine.backward_ranges = self.ranges
+            self.engine.range_hook = self._on_range
+
+    def slice_for(self, first: int, last: int) -> Tuple[int, int]:
+        off = self.prefix + last * self.block_numel
+        n = (first - last + 1) * self.block_numel
+        if last == 0:                                   # cls/pos/patch/final-norm grads are complete now too
+            off, n = 0, n + self.prefix
+        return off, n
+
+    def _on_range(self, engine, first: int, last: int):
+        off, n = self.slice_for(first, last)
+        self.reducer.reduce_slice(engine.grad_flat, off, n)
+
+    def finish(self):
+        """Call after loss.backward(): reduce the small head/KAN gradients, then join the side stream."""
+        if self.world == 1:
+            return
+        grads = [p.grad for p in self.other_params if p.grad is not None]
+        if grads:
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            self.reducer.reduce_slice(flat, 0, flat.numel())
+            self.reducer.finish(flat.device)
+            off = 0
+            for g in grads:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+        else:
+            self.reducer.finish()

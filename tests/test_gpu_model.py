@@ -116,7 +116,13 @@ def test_full_model_forward_all_stages_vs_oracle():
                 assert out[k] is None, (stage, k)
                 continue
             err = float((out[k].cpu() - r).abs().max())
-            assert out[k].shape == r.shape and err < BF16_TOL, (stage, k, err)
+            assert out[k].shape == r.shape
+            if k == 'kan_severity':
+                # The reference's truncated spline jumps to zero at x = atanh(knots[num_basis]),
+                # so features that differ by bf16 rounding flip a few basis terms and move the severity by
+                # O(0.1): end-to-end it is only comparable on identical features (checked to 1e-3 below).
+                continue
+            assert err < BF16_TOL, (stage, k, err)
         # class argmax: identical wherever the oracle's top-2 margin exceeds the stated tolerance
         top2 = ref['cls_logits'].topk(2, dim=1).values
         decided = (top2[:, 0] - top2[:, 1]) > 2 * BF16_TOL

@@ -39,10 +39,8 @@ __device__ __forceinline__ void stage_tile(bf16* dst, const bf16* src, int ld, i
   for (int i = 0; i < TP * 8 / (NW * 64); ++i) {
     const int c = tid + i * NW * 64;
     const int row = c >> 3, kc = c & 7;
-    bf16x8 v;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = (bf16)0.f;
-    if (row < T) v = *(const bf16x8*)(src + (size_t)row * ld + kc * 8);
+    const int rc = row < T ? row : T - 1;                       // clamped load + select: no branch around the load
+    const bf16x8 v = keep_if(*(const bf16x8*)(src + (size_t)rc * ld + kc * 8), row < T);
     *(bf16x8*)(dst + row * AST + kc * 8) = v;
   }
 }

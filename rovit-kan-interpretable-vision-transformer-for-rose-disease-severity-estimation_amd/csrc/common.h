@@ -63,6 +63,14 @@ __device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
   return r;
 }
 
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+// v if keep else zeros, as four dword selects (no branch, so the producing load is not waited for early)
+__device__ __forceinline__ bf16x8 keep_if(bf16x8 v, bool keep) {
+  u32x4 u = __builtin_bit_cast(u32x4, v);
+  u[0] = keep ? u[0] : 0u; u[1] = keep ? u[1] : 0u; u[2] = keep ? u[2] : 0u; u[3] = keep ? u[3] : 0u;
+  return __builtin_bit_cast(bf16x8, u);
+}
+
 __device__ __forceinline__ bf16x4 pack4(f32x4 v) {
   bf16x4 r;
   r[0] = (bf16)v[0]; r[1] = (bf16)v[1]; r[2] = (bf16)v[2]; r[3] = (bf16)v[3];
@@ -75,6 +83,15 @@ __device__ __forceinline__ bf16x4 pack4(f32x4 v) {
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt(0), which
+// would serialise every prefetched global load behind the barrier; plain loads are still waited for by the
+// compiler at their first use.
+__device__ __forceinline__ void barrier_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 
 __device__ __forceinline__ float wave_sum16(float v) {   // sum over the 16 lanes sharing l>>4
@@ -93,3 +110,21 @@ __device__ __forceinline__ float group4_max(float v) {
 }
 
 #endif  // __HIPCC__
+
+// ---- internal batched helpers (not part of the C ABI): many small problems in one launch, descriptors passed
+// by value in the kernel arguments ------------------------------------------------------------------------
+struct RovitPrepDesc {
+  const float* W; const float* bias; const float* gamma; const float* beta;
+  void* Wf; void* WfT; float* bias_f;
+  int N, K;
+};
+constexpr int ROVIT_PREP_BATCH = 24;
+int rovit_prep_weight_batch(const RovitPrepDesc* descs, int n, rovit_stream_t stream);
+
+struct RovitReduceDesc {
+  const float* ws; int splits, N, K;
+  const float* gamma; const float* beta; const float* W;      // gamma != NULL: un-fold the LayerNorm affine
+  float* dW; float* db; float* dgamma; float* dbeta; float* g_scratch;
+};
+constexpr int ROVIT_REDUCE_BATCH = 4;
+int rovit_wgrad_reduce_batch(const RovitReduceDesc* descs, int n, rovit_stream_t stream);

@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void cls_ln_affine_grad_kernel(const float* __
   const int d = blockIdx.x * 256 + threadIdx.x;
   if (d >= D) return;
   float sg = 0.f, sb = 0.f;
+#pragma unroll 8
   for (int b = 0; b < B; ++b) {
     const float g = dfeat[(size_t)b * D + d];
     sg = fmaf(g, xhat[(size_t)b * D + d], sg); sb += g;
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= T * D) return;
   float s = 0.f;
+#pragma unroll 8
   for (int b = 0; b < B; ++b) s += dX[(size_t)b * T * D + e];
   dpos[e] = s;
   if (e < D) dcls[e] = s;
@@ -215,7 +217,49 @@ __global__ __launch_bounds__(256) void prep_weight_kernel(const float* __restric
   }
 }
 
+struct PrepBatch { RovitPrepDesc d[ROVIT_PREP_BATCH]; int first_group[ROVIT_PREP_BATCH + 1]; int n; };
+
+__global__ __launch_bounds__(256) void prep_weight_batch_kernel(const PrepBatch pb) {
+  int i = 0;
+  while (i + 1 < pb.n && (int)blockIdx.x >= pb.first_group[i + 1]) ++i;
+  const RovitPrepDesc& d = pb.d[i];
+  const int n = ((int)blockIdx.x - pb.first_group[i]) * 16 + (threadIdx.x >> 4);
+  const int c = threadIdx.x & 15;
+  if (n >= d.N) return;
+  bf16* Wf = (bf16*)d.Wf;
+  bf16* WfT = (bf16*)d.WfT;
+  float dot = 0.f;
+  for (int k = c; k < d.K; k += 16) {
+    const float w = d.W[(size_t)n * d.K + k];
+    const float wf = d.gamma ? w * d.gamma[k] : w;
+    if (d.beta) dot = fmaf(w, d.beta[k], dot);
+    Wf[(size_t)n * d.K + k] = (bf16)wf;
+    if (WfT) WfT[(size_t)k * d.N + n] = (bf16)wf;
+  }
+  if (d.bias_f) {
+    dot = wave_sum16(dot);
+    if (c == 0) d.bias_f[n] = (d.bias ? d.bias[n] : 0.f) + dot;
+  }
+}
+
 }  // namespace
+
+int rovit_prep_weight_batch(const RovitPrepDesc* descs, int n, rovit_stream_t stream) {
+  for (int off = 0; off < n; off += ROVIT_PREP_BATCH) {
+    PrepBatch pb{};
+    pb.n = n - off < ROVIT_PREP_BATCH ? n - off : ROVIT_PREP_BATCH;
+    int groups = 0;
+    for (int i = 0; i < pb.n; ++i) {
+      pb.d[i] = descs[off + i];
+      pb.first_group[i] = groups;
+      groups += (pb.d[i].N + 15) / 16;
+    }
+    pb.first_group[pb.n] = groups;
+    hipLaunchKernelGGL(prep_weight_batch_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, pb);
+    ROVIT_CHECK_LAUNCH("prep_weight_batch_kernel");
+  }
+  return ROVIT_OK;
+}
 
 extern "C" int rovit_layernorm_fwd(const float* x, void* xhat, float* rstd, int rows, int dim, float eps, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(x && xhat && rstd, ROVIT_ERR_NULL, "layernorm_fwd: null pointer");

@@ -461,6 +461,7 @@ struct WgradArgs {
   int k_tiles, n_tiles;
 };
 
+template <bool PATCH>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   constexpr int CPR = WG_T / 8;                         // 12 chunks per row
   constexpr int CH = WG_MSTEP * CPR / 256;              // 3 chunks per thread per operand
@@ -481,32 +482,47 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   const int wk = wave >> 1, wn = wave & 1;              // wave tile: k rows [48*wk, +48), n cols [48*wn, +48)
   const int l15 = lane & 15, lg = lane >> 4;
 
-  int c_row[CH], c_col[CH];
+  // Per-thread staging chunks.  Keep the hot loop free of address arithmetic: one clamped row index and one
+  // 64-bit multiply-add per chunk and step; the LDS offsets are loop constants.
+  int c_row[CH], c_lds[CH];
+  const bf16* ybase[CH];
+  const bf16* abase[CH];
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     const int c = tid + i * 256;
-    c_row[i] = c / CPR; c_col[i] = (c - c_row[i] * CPR) * 8;
+    c_row[i] = c / CPR;
+    const int col = (c - c_row[i] * CPR) * 8;
+    c_lds[i] = c_row[i] * WG_STRIDE + col;
+    ybase[i] = g.dY + n0 + col;
+    abase[i] = g.A + k0 + col;
   }
+  const int m_last = g.M - 1;
   auto load = [&](int mbase, bf16x8* ry, bf16x8* ra) {
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      const int m = mbase + c_row[i];
-      bf16x8 z;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) z[q] = (bf16)0.f;
-      ry[i] = z; ra[i] = z;
-      if (m < m_end) {
-        const int yr = g.patch_tokens > 0 ? m + m / (g.patch_tokens - 1) + 1 : m;
-        ry[i] = *(const bf16x8*)(g.dY + (size_t)yr * g.ldy + n0 + c_col[i]);
-        ra[i] = *(const bf16x8*)(g.A + (size_t)m * g.lda + k0 + c_col[i]);
-      }
+      int m = mbase + c_row[i];
+      m = m < m_last ? m : m_last;                      // clamp (never branch around a load); tail rows are zeroed in store()
+      const int yr = PATCH ? m + m / (g.patch_tokens - 1) + 1 : m;
+      ry[i] = *(const bf16x8*)(ybase[i] + (size_t)yr * g.ldy);
+      ra[i] = *(const bf16x8*)(abase[i] + (size_t)m * g.lda);
     }
   };
-  auto store = [&](int buf, const bf16x8* ry, const bf16x8* ra) {
+  auto store = [&](int buf, int mbase, const bf16x8* ry, const bf16x8* ra) {
+    bf16* yd = Ys + buf * WG_MSTEP * WG_STRIDE;
+    bf16* ad = As + buf * WG_MSTEP * WG_STRIDE;
+    if (mbase + WG_MSTEP <= m_end) {                    // wave-uniform: full step
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      *(bf16x8*)(Ys + (buf * WG_MSTEP + c_row[i]) * WG_STRIDE + c_col[i]) = ry[i];
-      *(bf16x8*)(As + (buf * WG_MSTEP + c_row[i]) * WG_STRIDE + c_col[i]) = ra[i];
+      for (int i = 0; i < CH; ++i) {
+        *(bf16x8*)(yd + c_lds[i]) = ry[i];
+        *(bf16x8*)(ad + c_lds[i]) = ra[i];
+      }
+    } else {                                            // last, partial step of a split: zero the rows past m_end
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const bool live = mbase + c_row[i] < m_end;
+        *(bf16x8*)(yd + c_lds[i]) = keep_if(ry[i], live);
+        *(bf16x8*)(ad + c_lds[i]) = keep_if(ra[i], live);
+      }
     }
   };
 
@@ -520,19 +536,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   bf16x8 ones;
 #pragma unroll
   for (int q = 0; q < 8; ++q) ones[q] = (bf16)1.0f;
+  const bool do_colsum = (ktile == 0 && wk == 0);
 
-  bf16x8 ry[CH], ra[CH];
-  load(m_begin, ry, ra);
-  store(0, ry, ra);
-  __syncthreads();
   const int nsteps = (m_end - m_begin + WG_MSTEP - 1) / WG_MSTEP;
   // transposed-read lane address inside a [rows][WG_STRIDE] tile: row 4*lg + (l15>>2), col 4*(l15&3)
   const int tr_off = (4 * lg + (l15 >> 2)) * WG_STRIDE + 4 * (l15 & 3);
-  for (int s = 0; s < nsteps; ++s) {
-    const int cur = s & 1;
-    if (s + 1 < nsteps) load(m_begin + (s + 1) * WG_MSTEP, ry, ra);
-    const bf16* Yc = Ys + cur * WG_MSTEP * WG_STRIDE + tr_off + wn * 48;
-    const bf16* Ac = As + cur * WG_MSTEP * WG_STRIDE + tr_off + wk * 48;
+  const bf16* Ybase = Ys + tr_off + wn * 48;
+  const bf16* Abase = As + tr_off + wk * 48;
+  auto compute = [&](int cur) {
+    const bf16* Yc = Ybase + cur * WG_MSTEP * WG_STRIDE;
+    const bf16* Ac = Abase + cur * WG_MSTEP * WG_STRIDE;
 #pragma unroll
     for (int ms = 0; ms < WG_MSTEP / 32; ++ms) {
       bf16x8 fa[3], fy[3];
@@ -547,13 +560,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(fa[i], fy[j], acc[i][j]);      // D[k][n]
-      if (ktile == 0 && wk == 0) {
+      if (do_colsum) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) accb[j] = mfma16(ones, fy[j], accb[j]);
       }
     }
-    if (s + 1 < nsteps) store(cur ^ 1, ry, ra);
-    __syncthreads();
+  };
+  // Two register sets keep the global loads of steps s+1 and s+2 in flight while step s runs its MFMAs; the
+  // barrier waits for LDS only, so those loads are not drained at it.
+  bf16x8 ryA[CH], raA[CH], ryB[CH], raB[CH];
+  load(m_begin, ryA, raA);
+  store(0, m_begin, ryA, raA);
+  load(m_begin + WG_MSTEP, ryA, raA);
+  load(m_begin + 2 * WG_MSTEP, ryB, raB);
+  barrier_lds();
+  for (int s = 0; s < nsteps; s += 2) {
+    const int mb = m_begin + s * WG_MSTEP;
+    if (s + 1 < nsteps) store(1, mb + WG_MSTEP, ryA, raA);
+    load(mb + 3 * WG_MSTEP, ryA, raA);
+    compute(0);
+    barrier_lds();
+    if (s + 1 < nsteps) {
+      if (s + 2 < nsteps) store(0, mb + 2 * WG_MSTEP, ryB, raB);
+      load(mb + 4 * WG_MSTEP, ryB, raB);
+      compute(1);
+      barrier_lds();
+    }
   }
   float* slab = g.slab + (size_t)split * g.N * g.K;
 #pragma unroll
@@ -564,67 +596,68 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
       const int k = k0 + wk * 48 + i * 16 + lg * 4;
       *(float4*)(slab + (size_t)n * g.K + k) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     }
-    if (ktile == 0 && wk == 0 && lg == 0) g.colsum[(size_t)split * g.N + n] = accb[j][0];
+    if (do_colsum && lg == 0) g.colsum[(size_t)split * g.N + n] = accb[j][0];
   }
 }
 
-// sum the slabs of one wgrad; optionally un-fold the LayerNorm affine that was folded into the weight:
+// Sum the slabs of a weight gradient; optionally un-fold the LayerNorm affine that was folded into the weight:
 //   W_f = W * gamma (per k), b_f = b + W beta   =>   dW = gamma * G + beta (x) db,  dgamma = sum_n W G,
-//   dbeta = sum_n W db.  dgamma/dbeta are finished by wgrad_affine_kernel.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ colsum,
-                                                           int splits, int N, int K, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ dW,
-                                                           float* __restrict__ db, float* __restrict__ Gout) {
-  const int q = blockIdx.x * 256 + threadIdx.x;      // one float4 (4 consecutive k of one row n) per thread
-  const int total4 = N * K / 4;
+//   dbeta = sum_n W db  (finished by the affine kernel, which needs the complete db).
+struct ReduceBatch { RovitReduceDesc d[ROVIT_REDUCE_BATCH]; int first_block[ROVIT_REDUCE_BATCH + 1]; int n; };
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBatch rb) {
+  int i = 0;
+  while (i + 1 < rb.n && (int)blockIdx.x >= rb.first_block[i + 1]) ++i;
+  const RovitReduceDesc& d = rb.d[i];
+  const float* slab = d.ws;
+  const float* colsum = d.ws + (size_t)d.splits * d.N * d.K;
+  const int q = ((int)blockIdx.x - rb.first_block[i]) * 256 + threadIdx.x;
+  const int total4 = d.N * d.K / 4;
   if (q < total4) {
     const float4* sp = (const float4*)slab + q;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
-    for (int i = 0; i < splits; ++i) {
-      const float4 v = sp[(size_t)i * total4];
+    for (int j = 0; j < d.splits; ++j) {
+      const float4 v = sp[(size_t)j * total4];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    if (gamma) {
-      const int e = q * 4, n = e / K, k = e - n * K;
-      float cb = 0.f;
-      for (int i = 0; i < splits; ++i) cb += colsum[(size_t)i * N + n];
-      ((float4*)Gout)[q] = s;
-      const float4 g = *(const float4*)(gamma + k), bt = *(const float4*)(beta + k);
-      ((float4*)dW)[q] = make_float4(g.x * s.x + bt.x * cb, g.y * s.y + bt.y * cb, g.z * s.z + bt.z * cb, g.w * s.w + bt.w * cb);
-    } else {
-      ((float4*)dW)[q] = s;
-    }
+    // folded weights: keep the raw G; dW = gamma*G + beta (x) db is finished by the affine kernel (needs db)
+    ((float4*)(d.gamma ? d.g_scratch : d.dW))[q] = s;
   }
-  if (q < N) {
+  if (q < d.N) {
     float cb = 0.f;
-    for (int i = 0; i < splits; ++i) cb += colsum[(size_t)i * N + q];
-    db[q] = cb;
+#pragma unroll 8
+    for (int j = 0; j < d.splits; ++j) cb += colsum[(size_t)j * d.N + q];
+    d.db[q] = cb;
   }
 }
 
-// dgamma[k] = sum_n W[n][k] G[n][k];  dbeta[k] = sum_n W[n][k] db[n].  One workgroup = 32 columns x 8 row groups.
-__global__ __launch_bounds__(256) void wgrad_affine_kernel(const float* __restrict__ G, const float* __restrict__ W,
-                                                           const float* __restrict__ db, int N, int K,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ __launch_bounds__(256) void wgrad_affine_batch_kernel(const ReduceBatch rb) {
   __shared__ float s_g[8][32], s_b[8][32];
+  int i = 0;
+  while (i + 1 < rb.n && (int)blockIdx.x >= rb.first_block[i + 1]) ++i;
+  const RovitReduceDesc& d = rb.d[i];
   const int kc = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int k = blockIdx.x * 32 + kc;
+  const int k = ((int)blockIdx.x - rb.first_block[i]) * 32 + kc;
   float sg = 0.f, sb = 0.f;
-  if (k < K) {
+  if (k < d.K) {
+    const float gam = d.gamma[k], bet = d.beta[k];
 #pragma unroll 4
-    for (int n = grp; n < N; n += 8) {
-      const float w = W[(size_t)n * K + k];
-      sg = fmaf(w, G[(size_t)n * K + k], sg);
-      sb = fmaf(w, db[n], sb);
+    for (int n = grp; n < d.N; n += 8) {
+      const float w = d.W[(size_t)n * d.K + k];
+      const float G = d.g_scratch[(size_t)n * d.K + k];
+      const float cb = d.db[n];
+      d.dW[(size_t)n * d.K + k] = fmaf(gam, G, bet * cb);
+      sg = fmaf(w, G, sg);
+      sb = fmaf(w, cb, sb);
     }
   }
   s_g[grp][kc] = sg; s_b[grp][kc] = sb;
   __syncthreads();
-  if (grp == 0 && k < K) {
+  if (grp == 0 && k < d.K) {
 #pragma unroll
-    for (int i = 1; i < 8; ++i) { sg += s_g[i][kc]; sb += s_b[i][kc]; }
-    dgamma[k] = sg; dbeta[k] = sb;
+    for (int j = 1; j < 8; ++j) { sg += s_g[j][kc]; sb += s_b[j][kc]; }
+    d.dgamma[k] = sg; d.dbeta[k] = sb;
   }
 }
 
@@ -669,7 +702,7 @@ extern "C" size_t rovit_wgrad_workspace_bytes(int N, int K, int splits) {
 
 extern "C" int rovit_wgrad_splits(int M, int N, int K) {
   const int tiles = (N / WG_T) * (K / WG_T);
-  int s = (256 + tiles - 1) / tiles;               // ~1 workgroup per CU (slab traffic grows with the split count)
+  int s = (512 + tiles - 1) / tiles;               // ~2 workgroups per CU: measured best trade against slab traffic
   s = (s + 7) / 8 * 8;
   const int max_s = (M + WG_MSTEP - 1) / WG_MSTEP;
   if (s > max_s) s = max_s;
@@ -691,7 +724,8 @@ extern "C" int rovit_wgrad(const void* dY, int ldy, const void* A, int lda, int 
   g.k_tiles = K / WG_T; g.n_tiles = N / WG_T;
   // a split whose first row is past M still writes zeros, so the reduce can sum every slab
   const int nwg = splits * g.k_tiles * g.n_tiles;
-  hipLaunchKernelGGL(wgrad_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, g);
+  if (patch_tokens > 0) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, g);
   ROVIT_CHECK_LAUNCH("wgrad_kernel");
   return ROVIT_OK;
 }
@@ -699,19 +733,37 @@ extern "C" int rovit_wgrad(const void* dY, int ldy, const void* A, int lda, int 
 extern "C" int rovit_wgrad_reduce(const float* ws, int splits, int N, int K, const float* gamma, const float* beta,
                                   const float* W, float* dW, float* db, float* dgamma, float* dbeta, float* g_scratch,
                                   rovit_stream_t stream) {
-  ROVIT_CHECK_ARG(ws && dW && db, ROVIT_ERR_NULL, "wgrad_reduce: null pointer");
-  const float* slab = ws;
-  const float* colsum = ws + (size_t)splits * N * K;
-  if (gamma) ROVIT_CHECK_ARG(beta && W && dgamma && dbeta && g_scratch, ROVIT_ERR_NULL, "wgrad_reduce: affine un-fold needs beta/W/outputs");
-  const int total = N * K;
-  const int nthreads = total / 4 > N ? total / 4 : N;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, (hipStream_t)stream, slab, colsum, splits,
-                     N, K, gamma, beta, dW, db, g_scratch);
-  ROVIT_CHECK_LAUNCH("wgrad_reduce_kernel");
-  if (gamma) {
-    hipLaunchKernelGGL(wgrad_affine_kernel, dim3((K + 31) / 32), dim3(256), 0, (hipStream_t)stream, g_scratch, W, db, N, K,
-                       dgamma, dbeta);
-    ROVIT_CHECK_LAUNCH("wgrad_affine_kernel");
+  const RovitReduceDesc d{ws, splits, N, K, gamma, beta, W, dW, db, dgamma, dbeta, g_scratch};
+  return rovit_wgrad_reduce_batch(&d, 1, stream);
+}
+
+// reduce (and un-fold) up to ROVIT_REDUCE_BATCH weight gradients in two launches
+int rovit_wgrad_reduce_batch(const RovitReduceDesc* descs, int n, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(descs && n > 0 && n <= ROVIT_REDUCE_BATCH, ROVIT_ERR_SHAPE, "wgrad_reduce_batch: bad batch size %d", n);
+  ReduceBatch rb{}, ab{};
+  int blocks = 0, ablocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const RovitReduceDesc& d = descs[i];
+    ROVIT_CHECK_ARG(d.ws && d.dW && d.db, ROVIT_ERR_NULL, "wgrad_reduce_batch: null pointer");
+    rb.d[i] = d;
+    rb.first_block[i] = blocks;
+    const int nthreads = d.N * d.K / 4 > d.N ? d.N * d.K / 4 : d.N;
+    blocks += (nthreads + 255) / 256;
+    if (d.gamma) {
+      ROVIT_CHECK_ARG(d.beta && d.W && d.dgamma && d.dbeta && d.g_scratch, ROVIT_ERR_NULL, "wgrad_reduce_batch: affine un-fold needs beta/W/outputs");
+      ab.d[ab.n] = d;
+      ab.first_block[ab.n] = ablocks;
+      ablocks += (d.K + 31) / 32;
+      ab.n++;
+    }
+  }
+  rb.n = n; rb.first_block[n] = blocks;
+  ab.first_block[ab.n] = ablocks;
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rb);
+  ROVIT_CHECK_LAUNCH("wgrad_reduce_batch_kernel");
+  if (ab.n > 0) {
+    hipLaunchKernelGGL(wgrad_affine_batch_kernel, dim3(ablocks), dim3(256), 0, (hipStream_t)stream, ab);
+    ROVIT_CHECK_LAUNCH("wgrad_affine_batch_kernel");
   }
   return ROVIT_OK;
 }

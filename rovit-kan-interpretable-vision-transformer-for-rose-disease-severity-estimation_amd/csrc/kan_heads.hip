@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void kan_fwd_kernel(const float* __restrict__ 
     if (b >= B) continue;
     float acc = lb[o];
     const float* lwo = lw + (size_t)o * in_f;
+#pragma unroll 4
     for (int i = 0; i < in_f; ++i) {
       const int q = bl * in_f + i;
       acc = fmaf(s_x[q], lwo[i], acc);
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(256) void kan_bwd_dx_kernel(const float* __restrict
     const Basis4 bs = kan_basis<true>(xn, s_knots, nk, inv_h0, dv);
     const float* g = s_g + bl * out_f;
     float lin = 0.f, spl = 0.f;
+#pragma unroll 4
     for (int o = 0; o < out_f; ++o) {
       const float go = g[o];
       lin = fmaf(go, lw[(size_t)o * in_f + i], lin);
@@ -212,6 +214,7 @@ __global__ __launch_bounds__(256) void kan_bwd_dw_kernel(const float* __restrict
       else if (e < n_sp + out_f) { kind = 1; o = e - n_sp; }
       else { kind = 2; o = e - n_sp - out_f; }
       float acc = 0.f;
+#pragma unroll 8
       for (int bl = 0; bl < nbatch; ++bl) {
         const size_t q = (size_t)(c0 + bl) * out_f + o;
         const float g = act_grad(gy[q], y[q], act);
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(256) void lin_bwd_dx_kernel(const float* __restrict
   if (e >= B * in_f) return;
   const int b = e / in_f, i = e - b * in_f;
   float acc = 0.f;
+#pragma unroll 8
   for (int o = 0; o < out_f; ++o)
     acc = fmaf(clamp_gate(g[(size_t)b * out_f + o], yclamp, (size_t)b * out_f + o), w[(size_t)o * in_f + i], acc);
   if (mul) acc *= mul[e];
@@ -276,6 +280,7 @@ __global__ __launch_bounds__(256) void lin_bwd_dw_kernel(const float* __restrict
   if (e >= out_f * in_f) return;
   const int o = e / in_f, i = e - o * in_f;
   float acc = 0.f, accb = 0.f;
+#pragma unroll 8
   for (int b = 0; b < B; ++b) {
     const float gv = clamp_gate(g[(size_t)b * out_f + o], yclamp, (size_t)b * out_f + o);
     acc = fmaf(gv, x[(size_t)b * in_f + i], acc);

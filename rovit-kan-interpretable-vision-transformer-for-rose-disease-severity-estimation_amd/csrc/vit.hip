@@ -10,6 +10,8 @@
 //   attention out bf16 (M,192) + lse2 (B,3,T), act = gelu(pre) and dact = gelu'(pre) bf16 (M,768)
 //   LayerNorm affines are folded into the following Linear (W*gamma, b + W beta) by rovit_vit_prepare, so the
 //   GEMM operand is the normalised xhat itself and the wgrad recovers dgamma/dbeta from G = dY^T xhat.
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -54,7 +56,7 @@ struct Plan {          // byte offsets into the workspace
   size_t xhat1, rstd1, qkv, lse, o, xhat2, rstd2, act, dact;   // inside one block
   // backward temporaries
   size_t dX, dXb, dpre, dxhat, dO, dqkv;
-  size_t slab_qkv, slab_proj, slab_fc1, slab_fc2, slab_pe, gscr;
+  size_t slab_qkv, slab_proj, slab_fc1, slab_fc2, slab_pe, gscr, gscr2;
   int s_qkv, s_proj, s_fc1, s_fc2, s_pe;
   size_t total;
   Plan(int batch, int depth_, int training_) : B(batch), depth(depth_), training(training_) {
@@ -94,6 +96,7 @@ struct Plan {          // byte offsets into the workspace
       slab_fc2 = o; o = al(o + rovit_wgrad_workspace_bytes(D, MLP, s_fc2));
       slab_pe = o; o = al(o + rovit_wgrad_workspace_bytes(D, PD, s_pe));
       gscr = o; o = al(o + (size_t)MLP * D * 4);
+      gscr2 = o; o = al(o + (size_t)MLP * D * 4);
     }
     total = o;
   }
@@ -120,15 +123,18 @@ extern "C" int rovit_vit_prepare(const float* const* params, void* prep, int dep
   ROVIT_CHECK_ARG(params && prep && depth > 0, ROVIT_ERR_NULL, "vit_prepare: null pointer");
   const Prep P(depth);
   char* pb = (char*)prep;
-  RUN(rovit_prep_weight(params[P_PATCH_W], nullptr, nullptr, nullptr, pb + P.wpe, nullptr, nullptr, D, PD, stream));
+  std::vector<RovitPrepDesc> descs;
+  descs.reserve(1 + 4 * depth);
+  descs.push_back({params[P_PATCH_W], nullptr, nullptr, nullptr, pb + P.wpe, nullptr, nullptr, D, PD});
   for (int i = 0; i < depth; ++i) {
     const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
     char* q = pb + P.blk0 + (size_t)i * P.blk_stride;
-    RUN(rovit_prep_weight(bp[B_QKVW], bp[B_QKVB], bp[B_N1W], bp[B_N1B], q + P.wqkv, q + P.wqkvT, (float*)(q + P.bqkv), 3 * D, D, stream));
-    RUN(rovit_prep_weight(bp[B_PROJW], nullptr, nullptr, nullptr, q + P.wproj, q + P.wprojT, nullptr, D, D, stream));
-    RUN(rovit_prep_weight(bp[B_FC1W], bp[B_FC1B], bp[B_N2W], bp[B_N2B], q + P.wfc1, q + P.wfc1T, (float*)(q + P.bfc1), MLP, D, stream));
-    RUN(rovit_prep_weight(bp[B_FC2W], nullptr, nullptr, nullptr, q + P.wfc2, q + P.wfc2T, nullptr, D, MLP, stream));
+    descs.push_back({bp[B_QKVW], bp[B_QKVB], bp[B_N1W], bp[B_N1B], q + P.wqkv, q + P.wqkvT, (float*)(q + P.bqkv), 3 * D, D});
+    descs.push_back({bp[B_PROJW], nullptr, nullptr, nullptr, q + P.wproj, q + P.wprojT, nullptr, D, D});
+    descs.push_back({bp[B_FC1W], bp[B_FC1B], bp[B_N2W], bp[B_N2B], q + P.wfc1, q + P.wfc1T, (float*)(q + P.bfc1), MLP, D});
+    descs.push_back({bp[B_FC2W], nullptr, nullptr, nullptr, q + P.wfc2, q + P.wfc2T, nullptr, D, MLP});
   }
+  RUN(rovit_prep_weight_batch(descs.data(), (int)descs.size(), stream));
   return ROVIT_OK;
 }
 
@@ -199,26 +205,26 @@ extern "C" int rovit_vit_backward(const float* d_features, const float* const* p
     RUN(rovit_gemm_nt(dXb, D, q + P.wfc2T, D, M, MLP, D, nullptr, EPI_MUL, ws + L.dpre, MLP, nullptr, nullptr, 0, s + L.dact, MLP,
                       nullptr, 0, stream));
     RUN(rovit_wgrad(dXb, D, s + L.act, MLP, M, D, MLP, L.s_fc2, 0, (float*)(ws + L.slab_fc2), stream));
-    RUN(rovit_wgrad_reduce((const float*)(ws + L.slab_fc2), L.s_fc2, D, MLP, nullptr, nullptr, nullptr, bg[B_FC2W], bg[B_FC2B], nullptr,
-                           nullptr, nullptr, stream));
     RUN(rovit_gemm_nt(ws + L.dpre, MLP, q + P.wfc1T, MLP, M, D, MLP, nullptr, EPI_BF16, ws + L.dxhat, D, nullptr, nullptr, 0, nullptr, 0,
                       nullptr, 0, stream));
     RUN(rovit_wgrad(ws + L.dpre, MLP, s + L.xhat2, D, M, MLP, D, L.s_fc1, 0, (float*)(ws + L.slab_fc1), stream));
-    RUN(rovit_wgrad_reduce((const float*)(ws + L.slab_fc1), L.s_fc1, MLP, D, bp[B_N2W], bp[B_N2B], bp[B_FC1W], bg[B_FC1W], bg[B_FC1B],
-                           bg[B_N2W], bg[B_N2B], (float*)(ws + L.gscr), stream));
     RUN(rovit_layernorm_bwd(ws + L.dxhat, s + L.xhat2, (const float*)(s + L.rstd2), dX, dXb, M, D, stream));
     // ---- attention ----
     RUN(rovit_gemm_nt(dXb, D, q + P.wprojT, D, M, D, D, nullptr, EPI_BF16, ws + L.dO, D, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, stream));
     RUN(rovit_wgrad(dXb, D, s + L.o, D, M, D, D, L.s_proj, 0, (float*)(ws + L.slab_proj), stream));
-    RUN(rovit_wgrad_reduce((const float*)(ws + L.slab_proj), L.s_proj, D, D, nullptr, nullptr, nullptr, bg[B_PROJW], bg[B_PROJB], nullptr,
-                           nullptr, nullptr, stream));
     RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, ws + L.dqkv, batch, T, H, D / H, 0.125f, stream));
     RUN(rovit_gemm_nt(ws + L.dqkv, 3 * D, q + P.wqkvT, 3 * D, M, D, 3 * D, nullptr, EPI_BF16, ws + L.dxhat, D, nullptr, nullptr, 0, nullptr,
                       0, nullptr, 0, stream));
     RUN(rovit_wgrad(ws + L.dqkv, 3 * D, s + L.xhat1, D, M, 3 * D, D, L.s_qkv, 0, (float*)(ws + L.slab_qkv), stream));
-    RUN(rovit_wgrad_reduce((const float*)(ws + L.slab_qkv), L.s_qkv, 3 * D, D, bp[B_N1W], bp[B_N1B], bp[B_QKVW], bg[B_QKVW], bg[B_QKVB],
-                           bg[B_N1W], bg[B_N1B], (float*)(ws + L.gscr), stream));
     RUN(rovit_layernorm_bwd(ws + L.dxhat, s + L.xhat1, (const float*)(s + L.rstd1), dX, dXb, M, D, stream));
+    const RovitReduceDesc rd[4] = {
+        {(const float*)(ws + L.slab_fc2), L.s_fc2, D, MLP, nullptr, nullptr, nullptr, bg[B_FC2W], bg[B_FC2B], nullptr, nullptr, nullptr},
+        {(const float*)(ws + L.slab_fc1), L.s_fc1, MLP, D, bp[B_N2W], bp[B_N2B], bp[B_FC1W], bg[B_FC1W], bg[B_FC1B], bg[B_N2W], bg[B_N2B],
+         (float*)(ws + L.gscr)},
+        {(const float*)(ws + L.slab_proj), L.s_proj, D, D, nullptr, nullptr, nullptr, bg[B_PROJW], bg[B_PROJB], nullptr, nullptr, nullptr},
+        {(const float*)(ws + L.slab_qkv), L.s_qkv, 3 * D, D, bp[B_N1W], bp[B_N1B], bp[B_QKVW], bg[B_QKVW], bg[B_QKVB], bg[B_N1W], bg[B_N1B],
+         (float*)(ws + L.gscr2)}};
+    RUN(rovit_wgrad_reduce_batch(rd, 4, stream));
   }
   if (last_block == 0) {
     RUN(rovit_wgrad(dXb, D, ws + L.col, PD, batch * (T - 1), D, PD, L.s_pe, T, (float*)(ws + L.slab_pe), stream));

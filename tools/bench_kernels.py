@@ -89,13 +89,14 @@ def main():
         for name, N, K in (('wgrad qkv', 576, 192), ('wgrad proj', 192, 192), ('wgrad fc1', 768, 192), ('wgrad fc2', 192, 768)):
             dY = torch.randn(M, N, device=dev).to(bf)
             A = torch.randn(M, K, device=dev).to(bf)
-            s = lib.rovit_wgrad_splits(M, N, K)
-            ws = torch.empty(lib.rovit_wgrad_workspace_bytes(N, K, s) // 4, device=dev)
-            dW, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
-            t1 = timeit(lambda: native.call('rovit_wgrad', native.ptr(dY), N, native.ptr(A), K, M, N, K, s, 0, native.ptr(ws), sp), a.iters)
-            t2 = timeit(lambda: native.call('rovit_wgrad_reduce', native.ptr(ws), s, N, K, None, None, None, native.ptr(dW), native.ptr(db),
-                                            None, None, None, sp), a.iters)
-            print(f'{name:28s} splits={s:3d} wgrad {t1:7.1f} us ({2.0 * M * N * K / t1 / 1e6:6.1f} TF)  reduce {t2:6.1f} us', flush=True)
+            s0 = lib.rovit_wgrad_splits(M, N, K)
+            for s in (s0, 2 * s0, 4 * s0):
+                ws = torch.empty(lib.rovit_wgrad_workspace_bytes(N, K, s) // 4, device=dev)
+                dW, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+                t1 = timeit(lambda: native.call('rovit_wgrad', native.ptr(dY), N, native.ptr(A), K, M, N, K, s, 0, native.ptr(ws), sp), a.iters)
+                t2 = timeit(lambda: native.call('rovit_wgrad_reduce', native.ptr(ws), s, N, K, None, None, None, native.ptr(dW), native.ptr(db),
+                                                None, None, None, sp), a.iters)
+                print(f'{name:28s} splits={s:3d} wgrad {t1:7.1f} us ({2.0 * M * N * K / t1 / 1e6:6.1f} TF)  reduce {t2:6.1f} us', flush=True)
     if 'attn' in only:
         qkv = (torch.randn(M, 576, device=dev)).to(bf)
         out = torch.empty(M, 192, device=dev, dtype=bf)

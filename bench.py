@@ -117,17 +117,17 @@ def main():
     from models.rovit_kan import RoViTKAN
     from rovit_hip.losses import JointLoss
     from rovit_hip.parallel import GradSync
+    from rovit_hip.optim import RoViTAdamW
 
     torch.manual_seed(0)                                 # identical replica on every rank
     model = RoViTKAN(pretrained=False).to(dev).train()   # random-init DeiT-Tiny + KAN head, dropout 0.3, stage 4
     model.curriculum_stage = 4
-    opt = build_optimizer(model)
+    opt = RoViTAdamW(model, lr=1e-4, weight_decay=1e-4, max_grad_norm=1.0)   # clip_grad_norm_(1.0) + AdamW, backbone at lr/10
     loss_fn = JointLoss(1.0, 0.5, 0.5, 2.0, torch.ones(4, device=dev))
     sync = GradSync(model, buckets=args.buckets)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     images = torch.randn(args.batch, 3, 224, 224, device=dev, generator=g)
     labels = torch.randint(0, 4, (args.batch,), device=dev, generator=g)
-    params = [p for p in model.parameters()]
 
     def step():
         out = model(images)
@@ -135,7 +135,6 @@ def main():
         opt.zero_grad(set_to_none=True)
         loss.backward()
         sync.finish()
-        torch.nn.utils.clip_grad_norm_(params, 1.0)
         opt.step()
         return loss
 

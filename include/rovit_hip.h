@@ -134,6 +134,17 @@ int rovit_pos_grad(const float* dX, float* dpos, float* dcls, int batch, int tok
 int rovit_prep_weight(const float* W, const float* bias, const float* gamma, const float* beta, void* Wf, void* WfT,
                       float* bias_f, int N, int K, rovit_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Optimizer step on flat fp32 buffers: global-norm clipping + AdamW as the reference applies them
+ * (training/trainer.py:123-128,137-141 clip_grad_norm_(1.0); training/optimizer.py:7-32 AdamW).
+ * rovit_sq_norm_accum: *out_sq += sum g^2 (caller zeroes out_sq; several buffers may accumulate into one norm).
+ * rovit_adamw_flat: torch.optim.AdamW semantics; grad_scale = device scalar multiplied into g (clip coefficient)
+ * or NULL; t = 1-based step count for the bias correction.
+ * ------------------------------------------------------------------------------------------------------------ */
+int rovit_sq_norm_accum(const float* g, size_t n, float* out_sq, rovit_stream_t stream);
+int rovit_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, const float* grad_scale, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int t, rovit_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,7 +56,9 @@ __device__ __forceinline__ bf16x8 col_frag(const bf16* tile, int r0, int dt, int
   return cat4(lds_read_tr(p), lds_read_tr(p + 16 * AST));
 }
 
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
+// launch bound: 4 waves/SIMD (<= 128 VGPRs) so that TWO 7-wave workgroups share a CU (70 KB of LDS each) and one
+// stages its K/V tiles while the other computes.
+__global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) bf16 lds[];
   bf16* Ks = lds;
   bf16* Vs = lds + TP * AST;
@@ -96,29 +98,33 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
   float inv_l[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
+    // VALU budget matters here (7 waves share 4 SIMDs): raw max on the unscaled scores, the scale folded into
+    // one FMA in front of a bare v_exp_f32, and the key mask only on tiles that actually straddle T.
     float m = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < 13; ++kt)
+    for (int kt = 0; kt < 13; ++kt) {
+      if (16 * kt + 16 > a.T) {                      // wave-uniform
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = 16 * kt + 4 * lg + r;
-        const float s = key < a.T ? st[kt][qt][r] * c2 : -INFINITY;
-        st[kt][qt][r] = s;
-        m = fmaxf(m, s);
+        for (int r = 0; r < 4; ++r)
+          if (16 * kt + 4 * lg + r >= a.T) st[kt][qt][r] = -INFINITY;
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, st[kt][qt][r]);
+    }
     m = group4_max(m);
+    const float mc = m * c2;
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 13; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = exp2f(st[kt][qt][r] - m);
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][qt][r], c2, -mc));
         st[kt][qt][r] = p;
         l += p;
       }
     l = group4_sum(l);
     inv_l[qt] = 1.f / l;
-    if (lg == 0 && qrow[qt] < a.T && a.lse2) a.lse2[((size_t)b * a.H + h) * a.T + qrow[qt]] = m + log2f(l);
+    if (lg == 0 && qrow[qt] < a.T && a.lse2) a.lse2[((size_t)b * a.H + h) * a.T + qrow[qt]] = mc + log2f(l);
   }
 
   // O^T[d][q] = sum_key V[key][d] P[q][key]
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const AttnArgs a) {
     }
     d += __shfl_xor(d, 1);
     if (half == 0) {
-      s_del[row] = d;
+      s_del[row] = d * a.scale;                 // pre-scaled: dS = P * (dP*scale - delta*scale)
       s_lse[row] = row < a.T ? a.lse2[((size_t)b * a.H + h) * a.T + row] : 0.f;
     }
   }
@@ -236,9 +242,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const AttnArgs a) {
           dp = mfma16(g0, vf[kt][0], dp); dp = mfma16(g1, vf[kt][1], dp);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pr = kvalid[kt] ? exp2f(s[r] * c2 - lse_r[r]) : 0.f;
+            const float pr = kvalid[kt] ? __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse_r[r])) : 0.f;
             p[qt][kt][r] = pr;
-            ds[qt][kt][r] = pr * (dp[r] - del_r[r]) * a.scale;
+            ds[qt][kt][r] = pr * fmaf(dp[r], a.scale, -del_r[r]);
           }
         }
       }
@@ -301,8 +307,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const AttnArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = 32 * kb + 16 * kt + 4 * lg + r;
-            const float pr = key < a.T ? exp2f(s[r] * c2 - lq[qt]) : 0.f;
-            ds[kt][qt][r] = pr * (dp[r] - dq_[qt]) * a.scale;
+            const float pr = key < a.T ? __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lq[qt])) : 0.f;
+            ds[kt][qt][r] = pr * fmaf(dp[r], a.scale, -dq_[qt]);
           }
         }
       }

@@ -14,11 +14,12 @@ constexpr int D = 192;          // embed dim; one row = 16 lanes x 3 float4
 // 16 lanes per row; lane c holds elements {64*i + 4*c .. +3 : i = 0..2}: every load/store instruction of a
 // 16-lane group covers 256 (fp32) / 128 (bf16) contiguous bytes.
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, bf16* __restrict__ xhat,
-                                                     float* __restrict__ rstd, int M, float eps) {
+                                                     float* __restrict__ rstd, int M, float eps, size_t x_ld, size_t h_ld,
+                                                     size_t r_ld) {
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int c = threadIdx.x & 15;
   if (row >= M) return;
-  const float4* xr = (const float4*)(x + (size_t)row * D);
+  const float4* xr = (const float4*)(x + (size_t)row * x_ld);
   float4 v[3];
   float s = 0.f;
 #pragma unroll
@@ -31,25 +32,26 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
   }
   const float r = rsqrtf(wave_sum16(q) * (1.f / D) + eps);
-  bf16x4* o = (bf16x4*)(xhat + (size_t)row * D);
+  bf16x4* o = (bf16x4*)(xhat + (size_t)row * h_ld);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     f32x4 t = {v[i].x * r, v[i].y * r, v[i].z * r, v[i].w * r};
     o[16 * i + c] = pack4(t);
   }
-  if (c == 0) rstd[row] = r;
+  if (c == 0) rstd[(size_t)row * r_ld] = r;
 }
 
 // ---- LayerNorm backward (affine already folded into dxhat by the dgrad GEMM) -----------------------------
 // dX += rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat));  dXb = bf16(dX)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dxhat, const bf16* __restrict__ xhat,
                                                      const float* __restrict__ rstd, float* __restrict__ dX,
-                                                     bf16* __restrict__ dXb, int M) {
+                                                     bf16* __restrict__ dXb, int M, size_t ld, size_t r_ld) {
+  // every row-major operand uses the same row stride `ld` (D when dense, T*D for the CLS rows only)
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int c = threadIdx.x & 15;
   if (row >= M) return;
-  const bf16x4* gp = (const bf16x4*)(dxhat + (size_t)row * D);
-  const bf16x4* hp = (const bf16x4*)(xhat + (size_t)row * D);
+  const bf16x4* gp = (const bf16x4*)(dxhat + (size_t)row * ld);
+  const bf16x4* hp = (const bf16x4*)(xhat + (size_t)row * ld);
   float g[12], h[12];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -62,9 +64,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dx
     }
   }
   const float c1 = wave_sum16(s1) * (1.f / D), c2 = wave_sum16(s2) * (1.f / D);
-  const float r = rstd[row];
-  float4* xp = (float4*)(dX + (size_t)row * D);
-  bf16x4* bp = (bf16x4*)(dXb + (size_t)row * D);
+  const float r = rstd[(size_t)row * r_ld];
+  float4* xp = (float4*)(dX + (size_t)row * ld);
+  bf16x4* bp = (bf16x4*)(dXb + (size_t)row * ld);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     float4 v = xp[16 * i + c];
@@ -265,8 +267,25 @@ extern "C" int rovit_layernorm_fwd(const float* x, void* xhat, float* rstd, int 
   ROVIT_CHECK_ARG(x && xhat && rstd, ROVIT_ERR_NULL, "layernorm_fwd: null pointer");
   ROVIT_CHECK_ARG(dim == D && rows > 0, ROVIT_ERR_SHAPE, "layernorm_fwd: dim must be %d (got %d)", D, dim);
   ROVIT_CHECK_ARG(rovit_aligned16(x) && rovit_aligned16(xhat), ROVIT_ERR_ALIGN, "layernorm_fwd: alignment");
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, (bf16*)xhat, rstd, rows, eps);
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, (bf16*)xhat, rstd, rows, eps,
+                     (size_t)D, (size_t)D, (size_t)1);
   ROVIT_CHECK_LAUNCH("ln_fwd_kernel");
+  return ROVIT_OK;
+}
+
+// same on every `row_step`-th row of the dense buffers (the CLS rows: row_step = tokens); results stay in place
+int rovit_layernorm_fwd_rows(const float* x, void* xhat, float* rstd, int rows, int row_step, float eps, rovit_stream_t stream) {
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, (bf16*)xhat, rstd, rows, eps,
+                     (size_t)D * row_step, (size_t)D * row_step, (size_t)row_step);
+  ROVIT_CHECK_LAUNCH("ln_fwd_kernel");
+  return ROVIT_OK;
+}
+
+int rovit_layernorm_bwd_rows(const void* dxhat, const void* xhat, const float* rstd, float* dX, void* dXb, int rows, int row_step,
+                             rovit_stream_t stream) {
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const bf16*)dxhat,
+                     (const bf16*)xhat, rstd, dX, (bf16*)dXb, rows, (size_t)D * row_step, (size_t)row_step);
+  ROVIT_CHECK_LAUNCH("ln_bwd_kernel");
   return ROVIT_OK;
 }
 
@@ -275,7 +294,7 @@ extern "C" int rovit_layernorm_bwd(const void* dxhat, const void* xhat, const fl
   ROVIT_CHECK_ARG(dxhat && xhat && rstd && dX && dXb, ROVIT_ERR_NULL, "layernorm_bwd: null pointer");
   ROVIT_CHECK_ARG(dim == D && rows > 0, ROVIT_ERR_SHAPE, "layernorm_bwd: dim must be %d", D);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const bf16*)dxhat,
-                     (const bf16*)xhat, rstd, dX, (bf16*)dXb, rows);
+                     (const bf16*)xhat, rstd, dX, (bf16*)dXb, rows, (size_t)D, (size_t)1);
   ROVIT_CHECK_LAUNCH("ln_bwd_kernel");
   return ROVIT_OK;
 }

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256 * WK) void gemm_ws_kernel(const GemmArgs g, int
   gload(tile0);
   lstore(0);
   if (ntile > 1) gload(tile0 + 1);
-  __syncthreads();
+  barrier_lds();
 
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256 * WK) void gemm_ws_kernel(const GemmArgs g, int
           for (int j = 0; j < 3; ++j) xo[((i / WK) * 3 + j) * 64] = acc[i][j];
         }
       }
-      __syncthreads();
+      barrier_lds();
       const f32x4* xi = xch + ((size_t)(cur * 8 + wave) * TOWN * 3) * 64 + lane;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256 * WK) void gemm_ws_kernel(const GemmArgs g, int
           }
         }
       }
-      if (WK == 1) __syncthreads();
+      if (WK == 1) barrier_lds();
     } else {
       // bf16 outputs: stage the (acc + bias) tile in LDS, then write whole 384-byte rows with 16-byte lanes
       // (the accumulator layout alone would give 16 rows x 32 bytes per store instruction).
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256 * WK) void gemm_ws_kernel(const GemmArgs g, int
           }
         }
       }
-      __syncthreads();
+      barrier_lds();
 #pragma unroll
       for (int q = 0; q < (BM * 24 + NT - 1) / NT; ++q) {
         const int c = tid + q * NT;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256 * WK) void gemm_ws_kernel(const GemmArgs g, int
           }
         }
       }
-      __syncthreads();
+      barrier_lds();
     }
   }
 }
@@ -459,6 +459,7 @@ struct WgradArgs {
   float* colsum;        // [splits][N]
   int patch_tokens;     // >0: dY row of m is m + m/(T-1) + 1 (skip each image's cls row)
   int k_tiles, n_tiles;
+  int dbg;              // developer knob: bit 0 skip steady-state global loads, bit 1 skip MFMAs
 };
 
 template <bool PATCH>
@@ -536,7 +537,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   bf16x8 ones;
 #pragma unroll
   for (int q = 0; q < 8; ++q) ones[q] = (bf16)1.0f;
-  const bool do_colsum = (ktile == 0 && wk == 0);
+  // bias gradient: one extra MFMA per 16 columns against a tile of ones.  The waves that hold the same dY
+  // fragments (same n-tile: 2 wk x k_tiles workgroups) share the three column tiles between them.
+  const int cs_owner = ktile * 2 + wk, cs_n = 2 * g.k_tiles;
+  const bool cs_do[3] = {0 % cs_n == cs_owner, 1 % cs_n == cs_owner, 2 % cs_n == cs_owner};
 
   const int nsteps = (m_end - m_begin + WG_MSTEP - 1) / WG_MSTEP;
   // transposed-read lane address inside a [rows][WG_STRIDE] tile: row 4*lg + (l15>>2), col 4*(l15&3)
@@ -560,10 +564,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(fa[i], fy[j], acc[i][j]);      // D[k][n]
-      if (do_colsum) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) accb[j] = mfma16(ones, fy[j], accb[j]);
-      }
+      for (int j = 0; j < 3; ++j)
+        if (cs_do[j]) accb[j] = mfma16(ones, fy[j], accb[j]);
     }
   };
   // Two register sets keep the global loads of steps s+1 and s+2 in flight while step s runs its MFMAs; the
@@ -577,13 +580,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   for (int s = 0; s < nsteps; s += 2) {
     const int mb = m_begin + s * WG_MSTEP;
     if (s + 1 < nsteps) store(1, mb + WG_MSTEP, ryA, raA);
-    load(mb + 3 * WG_MSTEP, ryA, raA);
-    compute(0);
+    if (!(g.dbg & 1)) load(mb + 3 * WG_MSTEP, ryA, raA);
+    if (!(g.dbg & 2)) compute(0);
     barrier_lds();
     if (s + 1 < nsteps) {
       if (s + 2 < nsteps) store(0, mb + 2 * WG_MSTEP, ryB, raB);
-      load(mb + 4 * WG_MSTEP, ryB, raB);
-      compute(1);
+      if (!(g.dbg & 1)) load(mb + 4 * WG_MSTEP, ryB, raB);
+      if (!(g.dbg & 2)) compute(1);
       barrier_lds();
     }
   }
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
       const int k = k0 + wk * 48 + i * 16 + lg * 4;
       *(float4*)(slab + (size_t)n * g.K + k) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     }
-    if (do_colsum && lg == 0) g.colsum[(size_t)split * g.N + n] = accb[j][0];
+    if (cs_do[j] && lg == 0) g.colsum[(size_t)split * g.N + n] = accb[j][0];
   }
 }
 
@@ -630,20 +633,25 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBat
     for (int j = 0; j < d.splits; ++j) cb += colsum[(size_t)j * d.N + q];
     d.db[q] = cb;
   }
+  if (d.gamma && q < d.K) { d.dgamma[q] = 0.f; d.dbeta[q] = 0.f; }     // accumulated by the affine kernel
 }
 
+constexpr int AFFINE_SLICES = 8;
 __global__ __launch_bounds__(256) void wgrad_affine_batch_kernel(const ReduceBatch rb) {
   __shared__ float s_g[8][32], s_b[8][32];
   int i = 0;
   while (i + 1 < rb.n && (int)blockIdx.x >= rb.first_block[i + 1]) ++i;
   const RovitReduceDesc& d = rb.d[i];
   const int kc = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int k = ((int)blockIdx.x - rb.first_block[i]) * 32 + kc;
+  const int local = (int)blockIdx.x - rb.first_block[i];
+  const int k = (local / AFFINE_SLICES) * 32 + kc;
+  const int sl = local % AFFINE_SLICES;                  // this block's slice of the rows n
+  const int n_lo = (int)((long)d.N * sl / AFFINE_SLICES), n_hi = (int)((long)d.N * (sl + 1) / AFFINE_SLICES);
   float sg = 0.f, sb = 0.f;
   if (k < d.K) {
     const float gam = d.gamma[k], bet = d.beta[k];
 #pragma unroll 4
-    for (int n = grp; n < d.N; n += 8) {
+    for (int n = n_lo + grp; n < n_hi; n += 8) {
       const float w = d.W[(size_t)n * d.K + k];
       const float G = d.g_scratch[(size_t)n * d.K + k];
       const float cb = d.db[n];
@@ -657,7 +665,8 @@ __global__ __launch_bounds__(256) void wgrad_affine_batch_kernel(const ReduceBat
   if (grp == 0 && k < d.K) {
 #pragma unroll
     for (int j = 1; j < 8; ++j) { sg += s_g[j][kc]; sb += s_b[j][kc]; }
-    d.dgamma[k] = sg; d.dbeta[k] = sb;
+    atomicAdd(d.dgamma + k, sg);                         // AFFINE_SLICES partial sums per column; zeroed by the reduce kernel
+    atomicAdd(d.dbeta + k, sb);
   }
 }
 
@@ -721,7 +730,7 @@ extern "C" int rovit_wgrad(const void* dY, int ldy, const void* A, int lda, int 
   g.rows_per_split = ((M + splits - 1) / splits + WG_MSTEP - 1) / WG_MSTEP * WG_MSTEP;
   g.slab = ws; g.colsum = ws + (size_t)splits * N * K;
   g.patch_tokens = patch_tokens;
-  g.k_tiles = K / WG_T; g.n_tiles = N / WG_T;
+  g.k_tiles = K / WG_T; g.n_tiles = N / WG_T; g.dbg = g_gemm_dbg >> 4;
   // a split whose first row is past M still writes zeros, so the reduce can sum every slab
   const int nwg = splits * g.k_tiles * g.n_tiles;
   if (patch_tokens > 0) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, g);
@@ -753,7 +762,7 @@ int rovit_wgrad_reduce_batch(const RovitReduceDesc* descs, int n, rovit_stream_t
       ROVIT_CHECK_ARG(d.beta && d.W && d.dgamma && d.dbeta && d.g_scratch, ROVIT_ERR_NULL, "wgrad_reduce_batch: affine un-fold needs beta/W/outputs");
       ab.d[ab.n] = d;
       ab.first_block[ab.n] = ablocks;
-      ablocks += (d.K + 31) / 32;
+      ablocks += (d.K + 31) / 32 * AFFINE_SLICES;
       ab.n++;
     }
   }

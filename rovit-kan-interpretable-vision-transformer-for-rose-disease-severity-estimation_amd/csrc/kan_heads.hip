@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256) void kan_bwd_dw_kernel(const float* __restrict
   float* s_knots = smem;
   float* s_x = s_knots + KAN_MAX_KNOTS;      // BC
   float* s_d = s_x + BC;                     // BC * nb dense basis of feature i
+  float* s_gz = s_d + BC * (nk - 4);         // BC * out_f  dL/dz of this batch chunk (read many times below)
   const int tid = threadIdx.x;
   const int nb = nk - 4;
   const int i = blockIdx.x;
@@ -207,6 +208,10 @@ __global__ __launch_bounds__(256) void kan_bwd_dw_kernel(const float* __restrict
       }
       s_x[bl] = xv;
     }
+    for (int e = tid; e < nbatch * out_f; e += 256) {
+      const size_t q = (size_t)c0 * out_f + e;
+      s_gz[e] = act_grad(gy[q], y[q], act);
+    }
     __syncthreads();
     for (int e = tid; e < n_items; e += 256) {
       int o, k = -1, kind;                    // kind 0: spline weight, 1: linear weight, 2: linear bias
@@ -216,8 +221,7 @@ __global__ __launch_bounds__(256) void kan_bwd_dw_kernel(const float* __restrict
       float acc = 0.f;
 #pragma unroll 8
       for (int bl = 0; bl < nbatch; ++bl) {
-        const size_t q = (size_t)(c0 + bl) * out_f + o;
-        const float g = act_grad(gy[q], y[q], act);
+        const float g = s_gz[bl * out_f + o];
         const float m = kind == 0 ? s_d[bl * nb + k] : (kind == 1 ? s_x[bl] : 1.f);
         acc = fmaf(g, m, acc);
       }
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(256) void kan_basis_kernel(const float* __restrict_
   }
 }
 
-int kan_tb(int out_f) { int tb = 256 / (out_f > 0 ? out_f : 1); return tb < 1 ? 1 : (tb > 16 ? 16 : tb); }
+int kan_tb(int out_f) { int tb = 64 / (out_f > 0 ? out_f : 1); return tb < 1 ? 1 : (tb > 16 ? 16 : tb); }
 
 }  // namespace
 
@@ -356,9 +360,11 @@ extern "C" int rovit_kan_layer_bwd(const float* x, const float* spline_w, const 
   if (d_spline_w) {
     ROVIT_CHECK_ARG(d_lin_w && d_lin_b, ROVIT_ERR_NULL, "kan_layer_bwd: parameter gradients must be given together");
     const int nb = n_knots - 4;
-    int bc = (20 * 1024) / nb;                 // dense basis rows kept in LDS (<= 80 KB)
+    int bc = (24 * 1024) / (nb + 1 + out_f);   // batch rows whose basis + dL/dz stay in LDS (<= 96 KB)
     bc = bc > batch ? batch : bc;
-    const size_t lds = (KAN_MAX_KNOTS + (size_t)bc * (nb + 1)) * sizeof(float);
+    const size_t lds = (KAN_MAX_KNOTS + (size_t)bc * (nb + 1 + out_f)) * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kan_bwd_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); attr = true; }
     hipLaunchKernelGGL(kan_bwd_dw_kernel, dim3(in_f), dim3(256), lds, (hipStream_t)stream, x, knots, out, grad_out,
                        d_spline_w, d_lin_w, d_lin_b, batch, in_f, out_f, n_knots, bc, act);
     ROVIT_CHECK_LAUNCH("kan_bwd_dw_kernel");

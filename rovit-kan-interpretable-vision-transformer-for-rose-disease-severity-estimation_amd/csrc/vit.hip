@@ -58,6 +58,7 @@ struct Plan {          // byte offsets into the workspace
   size_t dX, dXb, dpre, dxhat, dO, dqkv;
   size_t slab_qkv, slab_proj, slab_fc1, slab_fc2, slab_pe, gscr, gscr2;
   int s_qkv, s_proj, s_fc1, s_fc2, s_pe;
+  int s_projc, s_fc1c, s_fc2c;      // split counts when only the B CLS rows are processed (last block)
   size_t total;
   Plan(int batch, int depth_, int training_) : B(batch), depth(depth_), training(training_) {
     M = (size_t)B * T;
@@ -83,6 +84,9 @@ struct Plan {          // byte offsets into the workspace
     s_fc1 = rovit_wgrad_splits((int)M, MLP, D);
     s_fc2 = rovit_wgrad_splits((int)M, D, MLP);
     s_pe = rovit_wgrad_splits(B * (T - 1), D, PD);
+    s_projc = rovit_wgrad_splits(B, D, D);
+    s_fc1c = rovit_wgrad_splits(B, MLP, D);
+    s_fc2c = rovit_wgrad_splits(B, D, MLP);
     if (training) {
       dX = o; o = al(o + M * D * 4);
       dXb = o; o = al(o + M * D * 2);
@@ -162,11 +166,18 @@ extern "C" int rovit_vit_forward(const float* images, const float* const* params
     RUN(rovit_gemm_nt(s + L.xhat1, D, q + P.wqkv, D, M, 3 * D, D, (const float*)(q + P.bqkv), EPI_BF16, s + L.qkv, 3 * D, nullptr,
                       nullptr, 0, nullptr, 0, nullptr, 0, stream));
     RUN(rovit_attention_fwd(s + L.qkv, s + L.o, (float*)(s + L.lse), batch, T, H, D / H, 0.125f, stream));
-    RUN(rovit_gemm_nt(s + L.o, D, q + P.wproj, D, M, D, D, bp[B_PROJB], EPI_RESID, nullptr, 0, nullptr, X, D, nullptr, 0, nullptr, 0, stream));
-    RUN(rovit_layernorm_fwd(X, s + L.xhat2, (float*)(s + L.rstd2), M, D, eps, stream));
-    RUN(rovit_gemm_nt(s + L.xhat2, D, q + P.wfc1, D, M, MLP, D, (const float*)(q + P.bfc1), EPI_GELU, s + L.act, MLP,
+    // Only token 0 of the LAST block's output is consumed (final norm + heads), and everything after the
+    // attention is row-wise: run proj / LN2 / MLP of that block on the B CLS rows only (row step T).
+    const bool cls_only = (i == depth - 1);
+    const int Mr = cls_only ? batch : M, rs = cls_only ? T : 1;
+    RUN(rovit_gemm_nt(s + L.o, D * rs, q + P.wproj, D, Mr, D, D, bp[B_PROJB], EPI_RESID, nullptr, 0, nullptr, X, D * rs, nullptr, 0,
+                      nullptr, 0, stream));
+    if (cls_only) RUN(rovit_layernorm_fwd_rows(X, s + L.xhat2, (float*)(s + L.rstd2), batch, T, eps, stream));
+    else RUN(rovit_layernorm_fwd(X, s + L.xhat2, (float*)(s + L.rstd2), M, D, eps, stream));
+    RUN(rovit_gemm_nt(s + L.xhat2, D * rs, q + P.wfc1, D, Mr, MLP, D, (const float*)(q + P.bfc1), EPI_GELU, s + L.act, MLP * rs,
                       training ? s + L.dact : nullptr, nullptr, 0, nullptr, 0, nullptr, 0, stream));
-    RUN(rovit_gemm_nt(s + L.act, MLP, q + P.wfc2, MLP, M, D, MLP, bp[B_FC2B], EPI_RESID, nullptr, 0, nullptr, X, D, nullptr, 0, nullptr, 0, stream));
+    RUN(rovit_gemm_nt(s + L.act, MLP * rs, q + P.wfc2, MLP, Mr, D, MLP, bp[B_FC2B], EPI_RESID, nullptr, 0, nullptr, X, D * rs, nullptr, 0,
+                      nullptr, 0, stream));
   }
   RUN(rovit_cls_norm_fwd(X, params[P_NORM_W], params[P_NORM_B], features, (float*)(ws + L.xhat_cls), (float*)(ws + L.rstd_cls), batch,
                          T, eps, stream));
@@ -201,27 +212,39 @@ extern "C" int rovit_vit_backward(const float* d_features, const float* const* p
     float* const* bg = grads + P_BLOCK0 + B_COUNT * i;
     const char* q = pb + P.blk0 + (size_t)i * P.blk_stride;
     char* s = ws + L.blk0 + (size_t)i * L.blk_stride;
+    // the last block's post-attention half only ever sees gradient on the B CLS rows (see rovit_vit_forward)
+    const bool cls_only = (i == depth - 1);
+    const int Mr = cls_only ? batch : M, rs = cls_only ? T : 1;
+    const int s_fc2 = cls_only ? L.s_fc2c : L.s_fc2, s_fc1 = cls_only ? L.s_fc1c : L.s_fc1, s_proj = cls_only ? L.s_projc : L.s_proj;
     // ---- MLP ----
-    RUN(rovit_gemm_nt(dXb, D, q + P.wfc2T, D, M, MLP, D, nullptr, EPI_MUL, ws + L.dpre, MLP, nullptr, nullptr, 0, s + L.dact, MLP,
-                      nullptr, 0, stream));
-    RUN(rovit_wgrad(dXb, D, s + L.act, MLP, M, D, MLP, L.s_fc2, 0, (float*)(ws + L.slab_fc2), stream));
-    RUN(rovit_gemm_nt(ws + L.dpre, MLP, q + P.wfc1T, MLP, M, D, MLP, nullptr, EPI_BF16, ws + L.dxhat, D, nullptr, nullptr, 0, nullptr, 0,
-                      nullptr, 0, stream));
-    RUN(rovit_wgrad(ws + L.dpre, MLP, s + L.xhat2, D, M, MLP, D, L.s_fc1, 0, (float*)(ws + L.slab_fc1), stream));
-    RUN(rovit_layernorm_bwd(ws + L.dxhat, s + L.xhat2, (const float*)(s + L.rstd2), dX, dXb, M, D, stream));
+    RUN(rovit_gemm_nt(dXb, D * rs, q + P.wfc2T, D, Mr, MLP, D, nullptr, EPI_MUL, ws + L.dpre, MLP * rs, nullptr, nullptr, 0, s + L.dact,
+                      MLP * rs, nullptr, 0, stream));
+    RUN(rovit_wgrad(dXb, D * rs, s + L.act, MLP * rs, Mr, D, MLP, s_fc2, 0, (float*)(ws + L.slab_fc2), stream));
+    RUN(rovit_gemm_nt(ws + L.dpre, MLP * rs, q + P.wfc1T, MLP, Mr, D, MLP, nullptr, EPI_BF16, ws + L.dxhat, D * rs, nullptr, nullptr, 0,
+                      nullptr, 0, nullptr, 0, stream));
+    RUN(rovit_wgrad(ws + L.dpre, MLP * rs, s + L.xhat2, D * rs, Mr, MLP, D, s_fc1, 0, (float*)(ws + L.slab_fc1), stream));
+    if (cls_only) {
+      RUN(rovit_layernorm_bwd_rows(ws + L.dxhat, s + L.xhat2, (const float*)(s + L.rstd2), dX, dXb, batch, T, stream));
+      // attention backward reads dO for every query: rows other than CLS carry no gradient
+      ROVIT_CHECK_ARG(hipMemsetAsync(ws + L.dO, 0, (size_t)M * D * sizeof(bf16), (hipStream_t)stream) == hipSuccess, ROVIT_ERR_LAUNCH,
+                      "vit_backward: memset failed");
+    } else {
+      RUN(rovit_layernorm_bwd(ws + L.dxhat, s + L.xhat2, (const float*)(s + L.rstd2), dX, dXb, M, D, stream));
+    }
     // ---- attention ----
-    RUN(rovit_gemm_nt(dXb, D, q + P.wprojT, D, M, D, D, nullptr, EPI_BF16, ws + L.dO, D, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, stream));
-    RUN(rovit_wgrad(dXb, D, s + L.o, D, M, D, D, L.s_proj, 0, (float*)(ws + L.slab_proj), stream));
+    RUN(rovit_gemm_nt(dXb, D * rs, q + P.wprojT, D, Mr, D, D, nullptr, EPI_BF16, ws + L.dO, D * rs, nullptr, nullptr, 0, nullptr, 0, nullptr,
+                      0, stream));
+    RUN(rovit_wgrad(dXb, D * rs, s + L.o, D * rs, Mr, D, D, s_proj, 0, (float*)(ws + L.slab_proj), stream));
     RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, ws + L.dqkv, batch, T, H, D / H, 0.125f, stream));
     RUN(rovit_gemm_nt(ws + L.dqkv, 3 * D, q + P.wqkvT, 3 * D, M, D, 3 * D, nullptr, EPI_BF16, ws + L.dxhat, D, nullptr, nullptr, 0, nullptr,
                       0, nullptr, 0, stream));
     RUN(rovit_wgrad(ws + L.dqkv, 3 * D, s + L.xhat1, D, M, 3 * D, D, L.s_qkv, 0, (float*)(ws + L.slab_qkv), stream));
     RUN(rovit_layernorm_bwd(ws + L.dxhat, s + L.xhat1, (const float*)(s + L.rstd1), dX, dXb, M, D, stream));
     const RovitReduceDesc rd[4] = {
-        {(const float*)(ws + L.slab_fc2), L.s_fc2, D, MLP, nullptr, nullptr, nullptr, bg[B_FC2W], bg[B_FC2B], nullptr, nullptr, nullptr},
-        {(const float*)(ws + L.slab_fc1), L.s_fc1, MLP, D, bp[B_N2W], bp[B_N2B], bp[B_FC1W], bg[B_FC1W], bg[B_FC1B], bg[B_N2W], bg[B_N2B],
+        {(const float*)(ws + L.slab_fc2), s_fc2, D, MLP, nullptr, nullptr, nullptr, bg[B_FC2W], bg[B_FC2B], nullptr, nullptr, nullptr},
+        {(const float*)(ws + L.slab_fc1), s_fc1, MLP, D, bp[B_N2W], bp[B_N2B], bp[B_FC1W], bg[B_FC1W], bg[B_FC1B], bg[B_N2W], bg[B_N2B],
          (float*)(ws + L.gscr)},
-        {(const float*)(ws + L.slab_proj), L.s_proj, D, D, nullptr, nullptr, nullptr, bg[B_PROJW], bg[B_PROJB], nullptr, nullptr, nullptr},
+        {(const float*)(ws + L.slab_proj), s_proj, D, D, nullptr, nullptr, nullptr, bg[B_PROJW], bg[B_PROJB], nullptr, nullptr, nullptr},
         {(const float*)(ws + L.slab_qkv), L.s_qkv, 3 * D, D, bp[B_N1W], bp[B_N1B], bp[B_QKVW], bg[B_QKVW], bg[B_QKVB], bg[B_N1W], bg[B_N1B],
          (float*)(ws + L.gscr2)}};
     RUN(rovit_wgrad_reduce_batch(rd, 4, stream));

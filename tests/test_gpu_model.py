@@ -191,3 +191,36 @@ def test_train_mode_dropout_runs_and_stage_gating_backward():
         expect = {'backbone', 'classification_head'} | ({'ordinal_head'} if stage >= 2 else set()) | \
                  ({'uncertainty_head'} if stage >= 3 else set()) | ({'kan_module'} if stage >= 4 else set())
         assert has == expect, (stage, has)
+
+
+def test_flat_adamw_matches_torch_clip_and_adamw():
+    """rovit_hip.optim.RoViTAdamW == clip_grad_norm_(1.0) + torch AdamW with the reference's two lr groups."""
+    import copy
+    from models.rovit_kan import RoViTKAN
+    from rovit_hip.optim import RoViTAdamW
+    from rovit_hip.losses import JointLoss
+    torch.manual_seed(0)
+    m1 = RoViTKAN(pretrained=False).to(dev()).eval()
+    m2 = copy.deepcopy(m1)
+    bb = [p for n, p in m2.named_parameters() if 'backbone' in n]
+    hd = [p for n, p in m2.named_parameters() if 'backbone' not in n]
+    ref_opt = torch.optim.AdamW([{'params': bb, 'lr': 1e-3 / 10}, {'params': hd, 'lr': 1e-3}], weight_decay=1e-2)
+    opt = RoViTAdamW(m1, lr=1e-3, weight_decay=1e-2, max_grad_norm=1.0)
+    x = torch.randn(2, 3, 224, 224, device=dev())
+    y = torch.tensor([0, 2], device=dev())
+    lf = JointLoss()
+    # ONE step from identical states: with bf16 GEMM operands the forward is a discontinuous function of the
+    # parameters at the 1e-2 level, so two optimizers that agree to 1e-8 still drift apart over several steps.
+    for m, o in ((m1, opt), (m2, ref_opt)):
+        o.zero_grad(set_to_none=True)
+        lf(m(x), y, y, 4)['total_loss'].backward()
+    before = {n: p.detach().clone() for n, p in m2.named_parameters()}
+    gn_ref = torch.nn.utils.clip_grad_norm_(m2.parameters(), 1.0)
+    ref_opt.step()
+    opt.step()
+    assert abs(float(opt.last_grad_norm) - float(gn_ref)) < 1e-4 * float(gn_ref)
+    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert n1 == n2
+        upd = float((p2.detach() - before[n2]).abs().max())
+        assert upd > 0, n1
+        assert float((p1.detach() - p2.detach()).abs().max()) < 2e-3 * upd + 1e-9, n1

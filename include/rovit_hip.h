@@ -106,6 +106,14 @@ int rovit_vit_backward(const float* d_features, const float* const* params, cons
 int rovit_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, int epi, void* out,
                   int ldo, void* out2, float* xres, int ldx, const void* mul, int ldm, const float* pos, int tokens,
                   rovit_stream_t stream);
+/* X(M,192) += bf16(A W^T + bias), fused with the LayerNorm that follows the residual add (timm Block: x = x + f(x);
+ * norm(x)): xhat_out bf16 (M,192) and rstd_out (M) of the updated rows; xhat_out NULL = residual add only. */
+int rovit_gemm_resid_ln(const void* A, int lda, const void* W, int ldw, int M, int K, const float* bias, float* X, void* xhat_out,
+                        float* rstd_out, float eps, rovit_stream_t stream);
+/* dgrad through a Linear that follows a LayerNorm, fused with that LayerNorm's backward:
+ * dxhat = dY W^T;  dX += rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat));  dXb = bf16(dX) */
+int rovit_gemm_ln_bwd(const void* dY, int ldy, const void* W, int ldw, int M, int K, const void* xhat, const float* rstd, float* dX,
+                      void* dXb, rovit_stream_t stream);
 int rovit_set_gemm_debug(int flags); /* developer knob: bit 0 skips the epilogue stores (timing experiments) */
 int rovit_set_gemm_tile(int tile); /* tuning knob: 0 = 128x192 tiles where N allows, 1 = 128x96 */
 /* G(N,K) = dY(M,N)^T A(M,K) and colsum(dY), split over M into `splits` fp32 slabs inside ws */

@@ -18,7 +18,7 @@ namespace {
 constexpr int BK = 64;
 constexpr int LDS_STRIDE = BK + 16;      // bf16 elements; 160-byte rows: conflict-free ds_read_b128 fragments
 
-enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_MUL = 3, EPI_PATCH = 4 };
+enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_MUL = 3, EPI_PATCH = 4, EPI_RESID_LN = 5, EPI_LNBWD = 6 };
 
 struct GemmArgs {
   const bf16* A; int lda;
@@ -31,6 +31,7 @@ struct GemmArgs {
   const bf16* mul; int ldm;
   const float* pos; int tokens;
   int n_tiles;
+  float* rstd_out; float eps;   // EPI_RESID_LN: statistics of the LayerNorm fused behind the residual add
   int dbg;            // developer knob (bit 0: skip epilogue stores, bit 1: skip MFMAs)
 };
 
@@ -287,7 +288,8 @@ __global__ __launch_bounds__(256 * WK) void gemm_ws_kernel(const GemmArgs g, int
         for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(wf[j][ks], af[i], acc[i][j]);     // D[n][m]
     }
     const int mbase = (g.dbg & 1) ? g.M : (tile0 + t) * BM;
-    constexpr bool STAGED = (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_MUL);
+    constexpr bool STAGED = (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_MUL || EPI == EPI_RESID_LN || EPI == EPI_LNBWD);
+    constexpr bool ROWWISE = (EPI == EPI_RESID_LN || EPI == EPI_LNBWD);
     if (WK == 2) {
       // partner = same wn, other wk.  Wave wk finishes row tiles i with (i % WK) == wk; it ships the others.
       f32x4* xo = xch + ((size_t)(cur * 8 + (wave ^ 4)) * TOWN * 3) * 64 + lane;    // partner's inbox
@@ -342,8 +344,81 @@ __global__ __launch_bounds__(256 * WK) void gemm_ws_kernel(const GemmArgs g, int
         }
       }
       barrier_lds();
+      if (ROWWISE) {
+        // Row-wise epilogues (N = 192 = one full LayerNorm row per tile row): 16 lanes per row, lane c holds
+        // elements {64 i + 4 c .. +3}; statistics by xor-shuffles inside the 16-lane group.
+        constexpr int RPP = NT / 16;
+        const int c = tid & 15;
 #pragma unroll
-      for (int q = 0; q < (BM * 24 + NT - 1) / NT; ++q) {
+        for (int pass = 0; pass < BM / RPP; ++pass) {
+          const int row = pass * RPP + (tid >> 4);
+          const int m = mbase + row;
+          if (m < g.M) {
+            float v[12];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              const bf16x4 t = *(const bf16x4*)(Cs + row * CSTR + 64 * i + 4 * c);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[4 * i + e] = (float)t[e];
+            }
+            float4* xp = (float4*)(g.xres + (size_t)m * g.ldx);
+            if (EPI == EPI_RESID_LN) {
+              // X += bf16(branch output); then (optionally) the next LayerNorm: xhat (bf16) and rstd
+              float sum = 0.f;
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+                float4 x = xp[16 * i + c];
+                x.x += v[4 * i]; x.y += v[4 * i + 1]; x.z += v[4 * i + 2]; x.w += v[4 * i + 3];
+                xp[16 * i + c] = x;
+                v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+                sum += x.x + x.y + x.z + x.w;
+              }
+              if (g.out) {
+                const float mean = wave_sum16(sum) * (1.f / 192.f);
+                float qs = 0.f;
+#pragma unroll
+                for (int e = 0; e < 12; ++e) { v[e] -= mean; qs += v[e] * v[e]; }
+                const float r = rsqrtf(wave_sum16(qs) * (1.f / 192.f) + g.eps);
+                bf16x4* hp = (bf16x4*)(g.out + (size_t)m * g.ldo);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                  f32x4 t = {v[4 * i] * r, v[4 * i + 1] * r, v[4 * i + 2] * r, v[4 * i + 3] * r};
+                  hp[16 * i + c] = pack4(t);
+                }
+                if (c == 0) g.rstd_out[m] = r;
+              }
+            } else {
+              // LayerNorm backward behind a dgrad: v = dxhat row (affine already folded into the weight),
+              // dX += rstd * (v - mean(v) - xhat * mean(v * xhat)); dXb = bf16(dX)
+              float h[12];
+              float s1 = 0.f, s2 = 0.f;
+              const bf16x4* hp = (const bf16x4*)(g.mul + (size_t)m * g.ldm);
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+                const bf16x4 t = hp[16 * i + c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { h[4 * i + e] = (float)t[e]; s1 += v[4 * i + e]; s2 += v[4 * i + e] * h[4 * i + e]; }
+              }
+              const float c1 = wave_sum16(s1) * (1.f / 192.f), c2 = wave_sum16(s2) * (1.f / 192.f);
+              const float r = g.pos[m];
+              bf16x4* bp = (bf16x4*)(g.out + (size_t)m * g.ldo);
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+                float4 x = xp[16 * i + c];
+                x.x += r * (v[4 * i] - c1 - h[4 * i] * c2);
+                x.y += r * (v[4 * i + 1] - c1 - h[4 * i + 1] * c2);
+                x.z += r * (v[4 * i + 2] - c1 - h[4 * i + 2] * c2);
+                x.w += r * (v[4 * i + 3] - c1 - h[4 * i + 3] * c2);
+                xp[16 * i + c] = x;
+                f32x4 t = {x.x, x.y, x.z, x.w};
+                bp[16 * i + c] = pack4(t);
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < (ROWWISE ? 0 : (BM * 24 + NT - 1) / NT); ++q) {
         const int c = tid + q * NT;
         const int row = c / 24, ch = c - row * 24;
         const int m = mbase + row;
@@ -403,7 +478,7 @@ int launch_ws(const GemmArgs& g0, int epi, hipStream_t st) {
     break;                                                                                                \
   }
   switch (epi) {
-    LAUNCHW(EPI_BF16) LAUNCHW(EPI_GELU) LAUNCHW(EPI_RESID) LAUNCHW(EPI_MUL) LAUNCHW(EPI_PATCH)
+    LAUNCHW(EPI_BF16) LAUNCHW(EPI_GELU) LAUNCHW(EPI_RESID) LAUNCHW(EPI_MUL) LAUNCHW(EPI_PATCH) LAUNCHW(EPI_RESID_LN) LAUNCHW(EPI_LNBWD)
     default: rovit_set_error("gemm_ws: unknown epilogue %d", epi); return ROVIT_ERR_SHAPE;
   }
 #undef LAUNCHW
@@ -775,4 +850,37 @@ int rovit_wgrad_reduce_batch(const RovitReduceDesc* descs, int n, rovit_stream_t
     ROVIT_CHECK_LAUNCH("wgrad_affine_batch_kernel");
   }
   return ROVIT_OK;
+}
+
+// X(M,192) += A(M,K) W(192,K)^T + bias (branch output rounded to bf16 first), fused with the LayerNorm that
+// follows the residual add: xhat_out (bf16) / rstd_out of the updated rows (pass NULL for no LayerNorm).
+extern "C" int rovit_gemm_resid_ln(const void* A, int lda, const void* W, int ldw, int M, int K, const float* bias, float* X,
+                                   void* xhat_out, float* rstd_out, float eps, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(A && W && X, ROVIT_ERR_NULL, "gemm_resid_ln: null pointer");
+  ROVIT_CHECK_ARG(M > 0 && (K == 192 || K == 576 || K == 768), ROVIT_ERR_SHAPE, "gemm_resid_ln: K must be 192/576/768 (got %d)", K);
+  ROVIT_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && rovit_aligned16(A) && rovit_aligned16(W) && rovit_aligned16(X), ROVIT_ERR_ALIGN,
+                  "gemm_resid_ln: alignment");
+  ROVIT_CHECK_ARG(!xhat_out || rstd_out, ROVIT_ERR_NULL, "gemm_resid_ln: rstd_out missing");
+  GemmArgs g{};
+  g.A = (const bf16*)A; g.lda = lda; g.W = (const bf16*)W; g.ldw = ldw; g.M = M; g.N = 192; g.K = K; g.bias = bias;
+  g.xres = X; g.ldx = 192; g.out = (bf16*)xhat_out; g.ldo = 192; g.rstd_out = rstd_out; g.eps = eps; g.dbg = g_gemm_dbg;
+  if (K == 192) return launch_ws<6, 1, 64>(g, EPI_RESID_LN, (hipStream_t)stream);
+  if (K == 576) return launch_ws<9, 2, 32>(g, EPI_RESID_LN, (hipStream_t)stream);
+  return launch_ws<12, 2, 32>(g, EPI_RESID_LN, (hipStream_t)stream);
+}
+
+// dgrad + LayerNorm backward: dxhat = dY(M,K) W(192,K)^T, then dX += rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)),
+// dXb = bf16(dX).  (W is the transposed folded weight, so the LayerNorm affine is already applied.)
+extern "C" int rovit_gemm_ln_bwd(const void* dY, int ldy, const void* W, int ldw, int M, int K, const void* xhat, const float* rstd,
+                                 float* dX, void* dXb, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(dY && W && xhat && rstd && dX && dXb, ROVIT_ERR_NULL, "gemm_ln_bwd: null pointer");
+  ROVIT_CHECK_ARG(M > 0 && (K == 192 || K == 576 || K == 768), ROVIT_ERR_SHAPE, "gemm_ln_bwd: K must be 192/576/768 (got %d)", K);
+  ROVIT_CHECK_ARG(ldy % 8 == 0 && ldw % 8 == 0 && rovit_aligned16(dY) && rovit_aligned16(W) && rovit_aligned16(dX), ROVIT_ERR_ALIGN,
+                  "gemm_ln_bwd: alignment");
+  GemmArgs g{};
+  g.A = (const bf16*)dY; g.lda = ldy; g.W = (const bf16*)W; g.ldw = ldw; g.M = M; g.N = 192; g.K = K;
+  g.mul = (const bf16*)xhat; g.ldm = 192; g.pos = rstd; g.xres = dX; g.ldx = 192; g.out = (bf16*)dXb; g.ldo = 192; g.dbg = g_gemm_dbg;
+  if (K == 192) return launch_ws<6, 1, 64>(g, EPI_LNBWD, (hipStream_t)stream);
+  if (K == 576) return launch_ws<9, 2, 32>(g, EPI_LNBWD, (hipStream_t)stream);
+  return launch_ws<12, 2, 32>(g, EPI_LNBWD, (hipStream_t)stream);
 }

@@ -162,7 +162,9 @@ extern "C" int rovit_vit_forward(const float* images, const float* const* params
     const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
     const char* q = pb + P.blk0 + (size_t)i * P.blk_stride;
     char* s = ws + L.blk0 + (size_t)i * L.blk_stride;
-    RUN(rovit_layernorm_fwd(X, s + L.xhat1, (float*)(s + L.rstd1), M, D, eps, stream));
+    // LayerNorm1 of block 0 is a kernel of its own; every other LayerNorm of the loop is fused into the epilogue
+    // of the GEMM that produces its input (proj -> norm2, fc2 -> next block's norm1).
+    if (i == 0) RUN(rovit_layernorm_fwd(X, s + L.xhat1, (float*)(s + L.rstd1), M, D, eps, stream));
     RUN(rovit_gemm_nt(s + L.xhat1, D, q + P.wqkv, D, M, 3 * D, D, (const float*)(q + P.bqkv), EPI_BF16, s + L.qkv, 3 * D, nullptr,
                       nullptr, 0, nullptr, 0, nullptr, 0, stream));
     RUN(rovit_attention_fwd(s + L.qkv, s + L.o, (float*)(s + L.lse), batch, T, H, D / H, 0.125f, stream));
@@ -170,14 +172,22 @@ extern "C" int rovit_vit_forward(const float* images, const float* const* params
     // attention is row-wise: run proj / LN2 / MLP of that block on the B CLS rows only (row step T).
     const bool cls_only = (i == depth - 1);
     const int Mr = cls_only ? batch : M, rs = cls_only ? T : 1;
-    RUN(rovit_gemm_nt(s + L.o, D * rs, q + P.wproj, D, Mr, D, D, bp[B_PROJB], EPI_RESID, nullptr, 0, nullptr, X, D * rs, nullptr, 0,
-                      nullptr, 0, stream));
-    if (cls_only) RUN(rovit_layernorm_fwd_rows(X, s + L.xhat2, (float*)(s + L.rstd2), batch, T, eps, stream));
-    else RUN(rovit_layernorm_fwd(X, s + L.xhat2, (float*)(s + L.rstd2), M, D, eps, stream));
+    if (cls_only) {
+      RUN(rovit_gemm_nt(s + L.o, D * rs, q + P.wproj, D, Mr, D, D, bp[B_PROJB], EPI_RESID, nullptr, 0, nullptr, X, D * rs, nullptr, 0,
+                        nullptr, 0, stream));
+      RUN(rovit_layernorm_fwd_rows(X, s + L.xhat2, (float*)(s + L.rstd2), batch, T, eps, stream));
+    } else {
+      RUN(rovit_gemm_resid_ln(s + L.o, D, q + P.wproj, D, M, D, bp[B_PROJB], X, s + L.xhat2, (float*)(s + L.rstd2), eps, stream));
+    }
     RUN(rovit_gemm_nt(s + L.xhat2, D * rs, q + P.wfc1, D, Mr, MLP, D, (const float*)(q + P.bfc1), EPI_GELU, s + L.act, MLP * rs,
                       training ? s + L.dact : nullptr, nullptr, 0, nullptr, 0, nullptr, 0, stream));
-    RUN(rovit_gemm_nt(s + L.act, MLP * rs, q + P.wfc2, MLP, Mr, D, MLP, bp[B_FC2B], EPI_RESID, nullptr, 0, nullptr, X, D * rs, nullptr, 0,
-                      nullptr, 0, stream));
+    if (cls_only) {
+      RUN(rovit_gemm_nt(s + L.act, MLP * rs, q + P.wfc2, MLP, Mr, D, MLP, bp[B_FC2B], EPI_RESID, nullptr, 0, nullptr, X, D * rs, nullptr, 0,
+                        nullptr, 0, stream));
+    } else {
+      char* sn = ws + L.blk0 + (size_t)(i + 1) * L.blk_stride;          // next block's saved-activation area
+      RUN(rovit_gemm_resid_ln(s + L.act, MLP, q + P.wfc2, MLP, M, MLP, bp[B_FC2B], X, sn + L.xhat1, (float*)(sn + L.rstd1), eps, stream));
+    }
   }
   RUN(rovit_cls_norm_fwd(X, params[P_NORM_W], params[P_NORM_B], features, (float*)(ws + L.xhat_cls), (float*)(ws + L.rstd_cls), batch,
                          T, eps, stream));
@@ -220,26 +230,27 @@ extern "C" int rovit_vit_backward(const float* d_features, const float* const* p
     RUN(rovit_gemm_nt(dXb, D * rs, q + P.wfc2T, D, Mr, MLP, D, nullptr, EPI_MUL, ws + L.dpre, MLP * rs, nullptr, nullptr, 0, s + L.dact,
                       MLP * rs, nullptr, 0, stream));
     RUN(rovit_wgrad(dXb, D * rs, s + L.act, MLP * rs, Mr, D, MLP, s_fc2, 0, (float*)(ws + L.slab_fc2), stream));
-    RUN(rovit_gemm_nt(ws + L.dpre, MLP * rs, q + P.wfc1T, MLP, Mr, D, MLP, nullptr, EPI_BF16, ws + L.dxhat, D * rs, nullptr, nullptr, 0,
-                      nullptr, 0, nullptr, 0, stream));
-    RUN(rovit_wgrad(ws + L.dpre, MLP * rs, s + L.xhat2, D * rs, Mr, MLP, D, s_fc1, 0, (float*)(ws + L.slab_fc1), stream));
     if (cls_only) {
+      RUN(rovit_gemm_nt(ws + L.dpre, MLP * rs, q + P.wfc1T, MLP, Mr, D, MLP, nullptr, EPI_BF16, ws + L.dxhat, D * rs, nullptr, nullptr, 0,
+                        nullptr, 0, nullptr, 0, stream));
+      RUN(rovit_wgrad(ws + L.dpre, MLP * rs, s + L.xhat2, D * rs, Mr, MLP, D, s_fc1, 0, (float*)(ws + L.slab_fc1), stream));
       RUN(rovit_layernorm_bwd_rows(ws + L.dxhat, s + L.xhat2, (const float*)(s + L.rstd2), dX, dXb, batch, T, stream));
       // attention backward reads dO for every query: rows other than CLS carry no gradient
       ROVIT_CHECK_ARG(hipMemsetAsync(ws + L.dO, 0, (size_t)M * D * sizeof(bf16), (hipStream_t)stream) == hipSuccess, ROVIT_ERR_LAUNCH,
                       "vit_backward: memset failed");
     } else {
-      RUN(rovit_layernorm_bwd(ws + L.dxhat, s + L.xhat2, (const float*)(s + L.rstd2), dX, dXb, M, D, stream));
+      // fc1 dgrad fused with the backward of norm2 (updates dX / dXb in place)
+      RUN(rovit_gemm_ln_bwd(ws + L.dpre, MLP, q + P.wfc1T, MLP, M, MLP, s + L.xhat2, (const float*)(s + L.rstd2), dX, dXb, stream));
+      RUN(rovit_wgrad(ws + L.dpre, MLP, s + L.xhat2, D, M, MLP, D, s_fc1, 0, (float*)(ws + L.slab_fc1), stream));
     }
     // ---- attention ----
     RUN(rovit_gemm_nt(dXb, D * rs, q + P.wprojT, D, Mr, D, D, nullptr, EPI_BF16, ws + L.dO, D * rs, nullptr, nullptr, 0, nullptr, 0, nullptr,
                       0, stream));
     RUN(rovit_wgrad(dXb, D * rs, s + L.o, D * rs, Mr, D, D, s_proj, 0, (float*)(ws + L.slab_proj), stream));
     RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, ws + L.dqkv, batch, T, H, D / H, 0.125f, stream));
-    RUN(rovit_gemm_nt(ws + L.dqkv, 3 * D, q + P.wqkvT, 3 * D, M, D, 3 * D, nullptr, EPI_BF16, ws + L.dxhat, D, nullptr, nullptr, 0, nullptr,
-                      0, nullptr, 0, stream));
+    // qkv dgrad fused with the backward of norm1
+    RUN(rovit_gemm_ln_bwd(ws + L.dqkv, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), dX, dXb, stream));
     RUN(rovit_wgrad(ws + L.dqkv, 3 * D, s + L.xhat1, D, M, 3 * D, D, L.s_qkv, 0, (float*)(ws + L.slab_qkv), stream));
-    RUN(rovit_layernorm_bwd(ws + L.dxhat, s + L.xhat1, (const float*)(s + L.rstd1), dX, dXb, M, D, stream));
     const RovitReduceDesc rd[4] = {
         {(const float*)(ws + L.slab_fc2), s_fc2, D, MLP, nullptr, nullptr, nullptr, bg[B_FC2W], bg[B_FC2B], nullptr, nullptr, nullptr},
         {(const float*)(ws + L.slab_fc1), s_fc1, MLP, D, bp[B_N2W], bp[B_N2B], bp[B_FC1W], bg[B_FC1W], bg[B_FC1B], bg[B_N2W], bg[B_N2B],

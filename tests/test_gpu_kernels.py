@@ -366,3 +366,48 @@ def test_attention_spiked_scores():
     ref, _ = _attn_ref(qkv, B, Tk, H)
     assert torch.isfinite(out.float()).all()
     assert float((out.float() - ref).abs().max()) < 3e-2
+
+
+@pytest.mark.parametrize('M,K', [(394, 192), (1000, 768), (77, 576)])
+def test_gemm_resid_ln_fused(M, K):
+    """X += bf16(A W^T + b) fused with the following LayerNorm (timm Block: x = x + f(x); norm(x))."""
+    native = _native()
+    torch.manual_seed(M + K)
+    A = bf(torch.randn(M, K, device=dev()))
+    W = bf(torch.randn(192, K, device=dev()) * 0.05)
+    bias = torch.randn(192, device=dev())
+    X0 = torch.randn(M, 192, device=dev()) * 2
+    X = X0.clone()
+    xhat = torch.empty(M, 192, device=dev(), dtype=torch.bfloat16)
+    rstd = torch.empty(M, device=dev())
+    native.call('rovit_gemm_resid_ln', native.ptr(A), K, native.ptr(W), K, M, K, native.ptr(bias), native.ptr(X), native.ptr(xhat),
+                native.ptr(rstd), 1e-6, native.stream_ptr())
+    ref_x = X0 + bf(A.float() @ W.float().t() + bias).float()
+    assert float((X - ref_x).abs().max()) < 2e-2                      # one bf16 ulp of the branch output
+    ref_h = torch.nn.functional.layer_norm(X, (192,), eps=1e-6)       # statistics of the row the kernel wrote
+    assert float((xhat.float() - ref_h).abs().max()) < 2e-2
+    assert relerr(rstd, 1 / torch.sqrt(X.var(1, unbiased=False) + 1e-6)) < 1e-5
+    X2 = X0.clone()                                                   # no LayerNorm requested: plain residual add
+    native.call('rovit_gemm_resid_ln', native.ptr(A), K, native.ptr(W), K, M, K, native.ptr(bias), native.ptr(X2), None, None, 1e-6,
+                native.stream_ptr())
+    assert torch.equal(X2, X)
+
+
+@pytest.mark.parametrize('M,K', [(394, 768), (1000, 576), (50, 192)])
+def test_gemm_ln_bwd_fused(M, K):
+    native = _native()
+    torch.manual_seed(M * 3 + K)
+    dY = bf(torch.randn(M, K, device=dev()))
+    W = bf(torch.randn(192, K, device=dev()) * 0.05)
+    xh = bf(torch.randn(M, 192, device=dev()))
+    rstd = torch.rand(M, device=dev()) + 0.5
+    dX0 = torch.randn(M, 192, device=dev())
+    dX = dX0.clone()
+    dXb = torch.empty(M, 192, device=dev(), dtype=torch.bfloat16)
+    native.call('rovit_gemm_ln_bwd', native.ptr(dY), K, native.ptr(W), K, M, K, native.ptr(xh), native.ptr(rstd), native.ptr(dX),
+                native.ptr(dXb), native.stream_ptr())
+    g = bf(dY.float() @ W.float().t()).float()                        # the dgrad output, rounded as the kernel stages it
+    h = xh.float()
+    ref = dX0 + rstd[:, None] * (g - g.mean(1, keepdim=True) - h * (g * h).mean(1, keepdim=True))
+    assert float((dX - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+    assert torch.equal(dXb, bf(dX))

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmArgs g)
 // each finishes half of the tile's rows.
 // ------------------------------------------------------------------------------------------------------
 template <int KS, int WK, int BM, int EPI>
-__global__ __launch_bounds__(256 * WK) void gemm_ws_kernel(const GemmArgs g, int tiles_per_wg, int n_tiles_m) {
+__global__ __launch_bounds__(256 * WK, 2) void gemm_ws_kernel(const GemmArgs g, int tiles_per_wg, int n_tiles_m) {
   constexpr int K = KS * 32 * WK;
   constexpr int NT = 256 * WK;
   constexpr int STR = K + 16;                  // LDS row stride: conflict-free ds_read_b128 for K = 192/576/768
@@ -245,8 +245,11 @@ __global__ __launch_bounds__(256 * WK) void gemm_ws_kernel(const GemmArgs g, int
     const int c = tid + i * NT;
     c_row[i] = c / CPR; c_col[i] = (c - c_row[i] * CPR) * 8;
   }
-  bf16x8 rv[CH];
-  auto gload = [&](int tile) {
+  // Two register sets keep the global loads of tiles t+1 and t+2 in flight while tile t is computed: with a
+  // single set the next load could only be issued after the previous one had landed (one tile per workgroup in
+  // flight = ~25 GB/s per CU, the measured ceiling of the first version of this kernel).
+  bf16x8 rvA[CH], rvB[CH];
+  auto gload = [&](int tile, bf16x8* rv) {
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       if (NCH % NT == 0 || tid + i * NT < NCH) {
@@ -256,21 +259,22 @@ __global__ __launch_bounds__(256 * WK) void gemm_ws_kernel(const GemmArgs g, int
       }
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const bf16x8* rv) {
 #pragma unroll
     for (int i = 0; i < CH; ++i)
       if (NCH % NT == 0 || tid + i * NT < NCH) *(bf16x8*)(As + (buf * BM + c_row[i]) * STR + c_col[i]) = rv[i];
   };
 
-  gload(tile0);
-  lstore(0);
-  if (ntile > 1) gload(tile0 + 1);
+  gload(tile0, rvA);
+  lstore(0, rvA);
+  if (ntile > 1) gload(tile0 + 1, rvA);
+  // A second register set (two tiles in flight per workgroup) was measured SLOWER here (spills at the 256-VGPR
+  // budget: qkv 26.4 -> 30.7 us), so it stays off; the code path is kept for shapes with a smaller W slice.
+  constexpr bool TWO_SETS = false;
+  if (TWO_SETS && ntile > 2) gload(tile0 + 2, rvB);
   barrier_lds();
 
-  for (int t = 0; t < ntile; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < ntile) lstore(cur ^ 1);           // tile t+1 (loaded during tile t-1's compute) -> other buffer
-    if (t + 2 < ntile) gload(tile0 + t + 2);      // in flight during this tile's MFMAs
+  auto tile_body = [&](int t, int cur) {
     f32x4 acc[TM][3];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -447,6 +451,25 @@ __global__ __launch_bounds__(256 * WK) void gemm_ws_kernel(const GemmArgs g, int
         }
       }
       barrier_lds();
+    }
+  };
+
+  if (TWO_SETS) {
+    for (int t = 0; t < ntile; t += 2) {
+      if (t + 1 < ntile) lstore(1, rvA);           // tile t+1 -> buffer 1 (its readers finished at the last barrier)
+      if (t + 3 < ntile) gload(tile0 + t + 3, rvA);
+      tile_body(t, 0);
+      if (t + 1 < ntile) {
+        if (t + 2 < ntile) lstore(0, rvB);         // tile t+2 -> buffer 0
+        if (t + 4 < ntile) gload(tile0 + t + 4, rvB);
+        tile_body(t + 1, 1);
+      }
+    }
+  } else {
+    for (int t = 0; t < ntile; ++t) {
+      if (t + 1 < ntile) lstore((t & 1) ^ 1, rvA);
+      if (t + 2 < ntile) gload(tile0 + t + 2, rvA);
+      tile_body(t, t & 1);
     }
   }
 }

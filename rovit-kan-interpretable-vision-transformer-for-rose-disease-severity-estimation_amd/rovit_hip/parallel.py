@@ -27,16 +27,17 @@ def block_ranges(depth: int, buckets: int) -> List[Tuple[int, int]]:
 class FlatBucketAllReduce:
     """Averaging all-reduce of slices of one flat gradient buffer, issued on a side stream as slices become ready."""
 
-    def __init__(self, group=None, use_side_stream: bool = True):
+    def __init__(self, group=None, use_side_stream: bool = True, force: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = force and dist.is_initialized()      # run the collectives even with one rank (code-path test)
         self.use_side_stream = use_side_stream
         self._stream: Optional[torch.cuda.Stream] = None
         self._pending = []
         self.issued: List[Tuple[int, int]] = []          # (offset, numel) log, for tests
 
     def _avg(self, t: torch.Tensor):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return None
         backend = dist.get_backend(self.group)
         if backend == 'nccl':
@@ -48,7 +49,7 @@ class FlatBucketAllReduce:
 
     def reduce_slice(self, flat: torch.Tensor, offset: int, numel: int):
         self.issued.append((offset, numel))
-        if self.world == 1 or numel == 0:
+        if (self.world == 1 and not self.force) or numel == 0:
             return
         piece = flat[offset:offset + numel]
         if flat.is_cuda and self.use_side_stream:
@@ -76,19 +77,20 @@ class FlatBucketAllReduce:
 class GradSync:
     """Wires FlatBucketAllReduce into a RoViTKAN model: backbone buckets overlap with backward, heads/KAN after."""
 
-    def __init__(self, model, buckets: int = 3, group=None):
+    def __init__(self, model, buckets: int = 3, group=None, force: bool = False):
         self.model = model
         self.engine = model.backbone.model.engine
         self.depth = model.backbone.model.depth
-        self.reducer = FlatBucketAllReduce(group)
+        self.reducer = FlatBucketAllReduce(group, force=force)
         self.world = self.reducer.world
+        self.active = self.world > 1 or self.reducer.force
         self.ranges = block_ranges(self.depth, buckets)
         params = model.backbone.model.ordered_parameters()
         sizes = [p.numel() for p in params]
         self.prefix = sum(sizes[:6])
         self.block_numel = sum(sizes[6:18])
         self.other_params = [p for n, p in model.named_parameters() if not n.startswith('backbone.')]
-        if self.world > 1:
+        if self.active:
             self.engine.backward_ranges = self.ranges
             self.engine.range_hook = self._on_range
 
@@ -105,16 +107,13 @@ class GradSync:
 
     def finish(self):
         """Call after loss.backward(): reduce the small head/KAN gradients, then join the side stream."""
-        if self.world == 1:
+        if not self.active:
             return
         grads = [p.grad for p in self.other_params if p.grad is not None]
         if grads:
-            flat = torch.cat([g.reshape(-1) for g in grads])
+            flat = torch._utils._flatten_dense_tensors(grads)            # one cat kernel
             self.reducer.reduce_slice(flat, 0, flat.numel())
             self.reducer.finish(flat.device)
-            off = 0
-            for g in grads:
-                g.copy_(flat[off:off + g.numel()].view_as(g))
-                off += g.numel()
+            torch._foreach_copy_(grads, torch._utils._unflatten_dense_tensors(flat, grads))   # one multi-tensor copy
         else:
             self.reducer.finish()

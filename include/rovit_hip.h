@@ -153,6 +153,20 @@ int rovit_sq_norm_accum(const float* g, size_t n, float* out_sq, rovit_stream_t 
 int rovit_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, const float* grad_scale, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int t, rovit_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Joint multi-task loss, forward + gradient in one launch: JointLoss.forward (training/losses.py:139-181) with
+ * FocalLoss (:15-38), OrdinalBCELoss (:48-72), UncertaintyLoss (:80-101), KANRegressionLoss (:109-114).
+ * Targets are int64 (torch.long).  NULL head pointers = head inactive at this curriculum stage.
+ * d_* = d(total)/d(head output) for an upstream gradient of 1; losses_out = [cls, ord, unc, kan, total].
+ * rovit_scale_buffers multiplies up to 5 buffers by a device scalar (chain rule with the upstream gradient).
+ * ------------------------------------------------------------------------------------------------------------ */
+int rovit_joint_loss(const float* cls_logits, const float* ordinal_logits, const float* mu, const float* log_var,
+                     const float* kan_severity, const long long* class_targets, const long long* severity_targets,
+                     const float* focal_alpha, float* d_cls, float* d_ord, float* d_mu, float* d_lv, float* d_kan,
+                     float* losses_out, int batch, int num_classes, float lambda_ord, float mu_unc, float nu_kan, float focal_gamma,
+                     rovit_stream_t stream);
+int rovit_scale_buffers(float* const* bufs, const int* counts, int n, const float* scale, rovit_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

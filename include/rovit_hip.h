@@ -64,7 +64,8 @@ int rovit_kan_layer_bwd(const float* x, const float* spline_w, const float* knot
  * 91-102) with the curriculum gate of RoViTKAN.forward (models/rovit_kan.py:93-116).
  * params[14] / grads[14] order: cls.fc1.{w,b} cls.fc2.{w,b} ord.fc1.{w,b} ord.fc2.{w,b} unc.fc1.{w,b}
  * unc.fc_mu.{w,b} unc.fc_logvar.{w,b}.  masks: HOST array of 3 device pointers (B,hid) holding the scaled
- * dropout keep-mask, or NULL / NULL entries in eval mode.  hidden: (3,B,hid) workspace kept for backward.
+ * dropout keep-mask, or NULL / NULL entries in eval mode.  hidden: (3,B,hid) workspace kept for backward;
+ * rovit_heads_bwd's scratch is (3,B,hid) as well.
  * ------------------------------------------------------------------------------------------------------------ */
 int rovit_linear_fwd(const float* x, const float* w, const float* bias, const float* mask, float* y, int batch, int in_f,
                      int out_f, int flags, rovit_stream_t stream);

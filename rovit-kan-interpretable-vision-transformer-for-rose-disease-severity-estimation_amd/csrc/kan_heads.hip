@@ -103,26 +103,49 @@ __global__ __launch_bounds__(256) void kan_fwd_kernel(const float* __restrict__ 
     *(float4*)(s_v + 4 * e) = make_float4(bs.v[0], bs.v[1], bs.v[2], bs.v[3]);
   }
   __syncthreads();
-  for (int e = tid; e < TB * out_f; e += 256) {
-    const int bl = e / out_f, o = e - bl * out_f, b = b0 + bl;
-    if (b >= B) continue;
-    float acc = lb[o];
-    const float* lwo = lw + (size_t)o * in_f;
+  // Contraction.  The (sample, output) items of this workgroup are few (<= 64 for the layer shapes of this
+  // model), so each item is shared by `nsplit` threads that each walk a slice of the input features (the loop is a
+  // chain of dependent L2 gathers; one thread per item left 3 of 4 waves idle and took ~30 us per layer).
+  float* s_part = (float*)(s_j + TB * in_f);            // [256] partial sums
+  const int items = TB * out_f;
+  const int nsplit = items >= 256 ? 1 : 256 / items;
+  for (int e0 = 0; e0 < items; e0 += 256) {
+    const int e = e0 + (nsplit == 1 ? tid : tid % items);
+    const int part = nsplit == 1 ? 0 : tid / items;
+    float acc = 0.f;
+    const bool live = e < items && part < nsplit;
+    const int bl = live ? e / out_f : 0, o = live ? e - bl * out_f : 0, b = b0 + bl;
+    if (live && b < B) {
+      const int chunk = (in_f + nsplit - 1) / nsplit;
+      const int i_lo = part * chunk, i_hi = min(in_f, i_lo + chunk);
+      const float* lwo = lw + (size_t)o * in_f;
 #pragma unroll 4
-    for (int i = 0; i < in_f; ++i) {
-      const int q = bl * in_f + i;
-      acc = fmaf(s_x[q], lwo[i], acc);
-      const int j = s_j[q];
-      if (j >= 0) {
-        const float4 v = *(const float4*)(s_v + 4 * q);
-        const float* w = W + ((size_t)i * out_f + o) * nb;
-        acc = fmaf(v.x, w[j], acc);
-        if (j >= 1) acc = fmaf(v.y, w[j - 1], acc);
-        if (j >= 2) acc = fmaf(v.z, w[j - 2], acc);
-        if (j >= 3) acc = fmaf(v.w, w[j - 3], acc);
+      for (int i = i_lo; i < i_hi; ++i) {
+        const int q = bl * in_f + i;
+        acc = fmaf(s_x[q], lwo[i], acc);
+        const int j = s_j[q];
+        if (j >= 0) {
+          const float4 v = *(const float4*)(s_v + 4 * q);
+          const float* w = W + ((size_t)i * out_f + o) * nb;
+          acc = fmaf(v.x, w[j], acc);
+          if (j >= 1) acc = fmaf(v.y, w[j - 1], acc);
+          if (j >= 2) acc = fmaf(v.z, w[j - 2], acc);
+          if (j >= 3) acc = fmaf(v.w, w[j - 3], acc);
+        }
       }
     }
-    out[(size_t)b * out_f + o] = act_apply(acc, act);
+    if (nsplit > 1) {
+      __syncthreads();
+      s_part[tid] = acc;
+      __syncthreads();
+      if (live && part == 0 && b < B) {
+        float t = lb[o];
+        for (int p = 0; p < nsplit; ++p) t += s_part[p * items + e];
+        out[(size_t)b * out_f + o] = act_apply(t, act);
+      }
+    } else if (live && b < B) {
+      out[(size_t)b * out_f + o] = act_apply(acc + lb[o], act);
+    }
   }
 }
 
@@ -208,6 +231,7 @@ __global__ __launch_bounds__(256) void kan_bwd_dw_kernel(const float* __restrict
       }
       s_x[bl] = xv;
     }
+#pragma unroll 8
     for (int e = tid; e < nbatch * out_f; e += 256) {
       const size_t q = (size_t)c0 * out_f + e;
       s_gz[e] = act_grad(gy[q], y[q], act);
@@ -315,6 +339,92 @@ __global__ __launch_bounds__(256) void kan_basis_kernel(const float* __restrict_
   }
 }
 
+// ---- batched variants: the heads are 3 + 4 tiny linears forward and 7 backward problems; running each as its own
+// launch costs more in launch gaps than in work, so they go out as 2 + 4 launches with the problem list passed by
+// value in the kernel arguments.
+struct LinFwdDesc { const float* x; const float* w; const float* bias; const float* mask; float* y; int in_f, out_f, flags; };
+struct LinFwdBatch { LinFwdDesc d[4]; int first[5]; int n, B; };
+
+__global__ __launch_bounds__(256) void lin_fwd_batch_kernel(const LinFwdBatch pb) {
+  int i = 0;
+  while (i + 1 < pb.n && (int)blockIdx.x >= pb.first[i + 1]) ++i;
+  const LinFwdDesc& d = pb.d[i];
+  const int e = ((int)blockIdx.x - pb.first[i]) * 256 + threadIdx.x;
+  if (e >= pb.B * d.out_f) return;
+  const int b = e / d.out_f, o = e - b * d.out_f;
+  const float4* xr = (const float4*)(d.x + (size_t)b * d.in_f);
+  const float4* wr = (const float4*)(d.w + (size_t)o * d.in_f);
+  float acc = d.bias ? d.bias[o] : 0.f;
+#pragma unroll 4
+  for (int k = 0; k < d.in_f / 4; ++k) {
+    const float4 a = xr[k], c = wr[k];
+    acc = fmaf(a.x, c.x, acc); acc = fmaf(a.y, c.y, acc); acc = fmaf(a.z, c.z, acc); acc = fmaf(a.w, c.w, acc);
+  }
+  if (d.flags & ROVIT_LIN_RELU) acc = fmaxf(acc, 0.f);
+  if (d.mask) acc *= d.mask[e];
+  if (d.flags & ROVIT_LIN_CLAMP10) acc = fminf(fmaxf(acc, -10.f), 10.f);
+  d.y[e] = acc;
+}
+
+// dx[b,i] (+)= (sum over sources s, outputs o of g_s[b,o] w_s[o,i]) * mul[b,i] * [pos[b,i] > 0]
+struct LinDxDesc { int nsrc; const float* g[3]; const float* w[3]; const float* yc[3]; int out_f[3];
+                   const float* mul; const float* pos; float* dx; int in_f, accumulate; };
+struct LinDxBatch { LinDxDesc d[3]; int first[4]; int n, B; };
+
+__global__ __launch_bounds__(256) void lin_bwd_dx_batch_kernel(const LinDxBatch pb) {
+  int i = 0;
+  while (i + 1 < pb.n && (int)blockIdx.x >= pb.first[i + 1]) ++i;
+  const LinDxDesc& d = pb.d[i];
+  const int e = ((int)blockIdx.x - pb.first[i]) * 256 + threadIdx.x;
+  if (e >= pb.B * d.in_f) return;
+  const int b = e / d.in_f, k = e - b * d.in_f;
+  float acc = 0.f;
+  for (int s = 0; s < d.nsrc; ++s) {
+#pragma unroll 8
+    for (int o = 0; o < d.out_f[s]; ++o) {
+      const size_t q = (size_t)b * d.out_f[s] + o;
+      acc = fmaf(clamp_gate(d.g[s][q], d.yc[s], q), d.w[s][(size_t)o * d.in_f + k], acc);
+    }
+  }
+  if (d.mul) acc *= d.mul[e];
+  if (d.pos) acc = d.pos[e] > 0.f ? acc : 0.f;
+  d.dx[e] = d.accumulate ? d.dx[e] + acc : acc;
+}
+
+struct LinDwDesc { const float* g; const float* x; const float* yc; float* dw; float* db; int in_f, out_f; };
+struct LinDwBatch { LinDwDesc d[4]; int first[5]; int n, B; };
+
+__global__ __launch_bounds__(256) void lin_bwd_dw_batch_kernel(const LinDwBatch pb) {
+  int i = 0;
+  while (i + 1 < pb.n && (int)blockIdx.x >= pb.first[i + 1]) ++i;
+  const LinDwDesc& d = pb.d[i];
+  const int e = ((int)blockIdx.x - pb.first[i]) * 256 + threadIdx.x;
+  if (e >= d.out_f * d.in_f) return;
+  const int o = e / d.in_f, k = e - o * d.in_f;
+  float acc = 0.f, accb = 0.f;
+#pragma unroll 8
+  for (int b = 0; b < pb.B; ++b) {
+    const size_t q = (size_t)b * d.out_f + o;
+    const float gv = clamp_gate(d.g[q], d.yc, q);
+    acc = fmaf(gv, d.x[(size_t)b * d.in_f + k], acc);
+    accb += gv;
+  }
+  d.dw[e] = acc;
+  if (k == 0) d.db[o] = accb;
+}
+
+template <class Batch, class Kernel>
+int launch_lin_batch(Batch& pb, int n, const int* work, Kernel kern, const char* name, hipStream_t st) {
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) { pb.first[i] = blocks; blocks += (work[i] + 255) / 256; }
+  pb.first[n] = blocks; pb.n = n;
+  if (blocks == 0) return ROVIT_OK;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st, pb);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { rovit_set_error("%s: launch failed: %s", name, hipGetErrorString(e)); return ROVIT_ERR_LAUNCH; }
+  return ROVIT_OK;
+}
+
 int kan_tb(int out_f) { int tb = 64 / (out_f > 0 ? out_f : 1); return tb < 1 ? 1 : (tb > 16 ? 16 : tb); }
 
 }  // namespace
@@ -335,7 +445,7 @@ extern "C" int rovit_kan_layer_fwd(const float* x, const float* spline_w, const 
   ROVIT_CHECK_ARG(n_knots >= 8 && n_knots <= KAN_MAX_KNOTS, ROVIT_ERR_SHAPE,
                   "kan_layer_fwd: degree-3 layer needs 8..%d knots, got %d", KAN_MAX_KNOTS, n_knots);
   const int tb = kan_tb(out_f);
-  const size_t lds = (KAN_MAX_KNOTS + (size_t)tb * in_f * 6) * sizeof(float);
+  const size_t lds = (KAN_MAX_KNOTS + (size_t)tb * in_f * 6 + 256) * sizeof(float);
   ROVIT_CHECK_ARG(lds <= 64 * 1024, ROVIT_ERR_SHAPE, "kan_layer_fwd: in_features %d too large for the LDS tile", in_f);
   hipLaunchKernelGGL(kan_fwd_kernel, dim3((batch + tb - 1) / tb), dim3(256), lds, (hipStream_t)stream, x, spline_w, knots,
                      lin_w, lin_b, out, batch, in_f, out_f, n_knots, tb, act);
@@ -411,61 +521,90 @@ extern "C" int rovit_linear_bwd(const float* x, const float* w, const float* gra
 //   [8] unc.fc1.w [9] unc.fc1.b [10] unc.fc_mu.w [11] unc.fc_mu.b [12] unc.fc_logvar.w [13] unc.fc_logvar.b
 // hidden: (3, B, hid) post-ReLU/dropout activations (saved for backward).  masks[h] may be NULL (eval).
 extern "C" int rovit_heads_fwd(const float* features, const float* const* params, const float* const* masks, float* hidden,
-                               float* cls_logits, float* ordinal_logits, float* mu, float* log_var, int batch, int embed,
-                               int hid, int num_classes, int stage, rovit_stream_t stream) {
+                               float* cls_logits, float* ordinal_logits, float* mu, float* log_var, int batch, int embed, int hid,
+                               int num_classes, int stage, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(features && params && hidden && cls_logits, ROVIT_ERR_NULL, "heads_fwd: null pointer");
   ROVIT_CHECK_ARG(stage >= 1 && stage <= 4, ROVIT_ERR_SHAPE, "heads_fwd: curriculum stage %d not in 1..4", stage);
+  ROVIT_CHECK_ARG(batch > 0 && embed % 4 == 0 && hid % 4 == 0, ROVIT_ERR_SHAPE, "heads_fwd: bad shape");
+  ROVIT_CHECK_ARG(stage < 2 || ordinal_logits, ROVIT_ERR_NULL, "heads_fwd: ordinal_logits is NULL at stage %d", stage);
+  ROVIT_CHECK_ARG(stage < 3 || (mu && log_var), ROVIT_ERR_NULL, "heads_fwd: mu/log_var is NULL at stage %d", stage);
   const size_t hs = (size_t)batch * hid;
-  int rc;
-#define RUN(call) do { rc = (call); if (rc != ROVIT_OK) return rc; } while (0)
-  RUN(rovit_linear_fwd(features, params[0], params[1], masks ? masks[0] : nullptr, hidden, batch, embed, hid, ROVIT_LIN_RELU, stream));
-  RUN(rovit_linear_fwd(hidden, params[2], params[3], nullptr, cls_logits, batch, hid, num_classes, 0, stream));
-  if (stage >= 2) {
-    ROVIT_CHECK_ARG(ordinal_logits, ROVIT_ERR_NULL, "heads_fwd: ordinal_logits is NULL at stage %d", stage);
-    RUN(rovit_linear_fwd(features, params[4], params[5], masks ? masks[1] : nullptr, hidden + hs, batch, embed, hid, ROVIT_LIN_RELU, stream));
-    RUN(rovit_linear_fwd(hidden + hs, params[6], params[7], nullptr, ordinal_logits, batch, hid, num_classes - 1, 0, stream));
+  const int nheads = stage >= 3 ? 3 : (stage >= 2 ? 2 : 1);
+  LinFwdBatch f1{}; f1.B = batch;
+  int work[4];
+  for (int h = 0; h < nheads; ++h) {
+    f1.d[h] = {features, params[4 * h], params[4 * h + 1], masks ? masks[h] : nullptr, hidden + h * hs, embed, hid, ROVIT_LIN_RELU};
+    work[h] = batch * hid;
   }
+  int rc = launch_lin_batch(f1, nheads, work, lin_fwd_batch_kernel, "lin_fwd_batch_kernel", (hipStream_t)stream);
+  if (rc) return rc;
+  LinFwdBatch f2{}; f2.B = batch;
+  int n = 0;
+  f2.d[n] = {hidden, params[2], params[3], nullptr, cls_logits, hid, num_classes, 0}; work[n++] = batch * num_classes;
+  if (stage >= 2) { f2.d[n] = {hidden + hs, params[6], params[7], nullptr, ordinal_logits, hid, num_classes - 1, 0}; work[n++] = batch * (num_classes - 1); }
   if (stage >= 3) {
-    ROVIT_CHECK_ARG(mu && log_var, ROVIT_ERR_NULL, "heads_fwd: mu/log_var is NULL at stage %d", stage);
-    RUN(rovit_linear_fwd(features, params[8], params[9], masks ? masks[2] : nullptr, hidden + 2 * hs, batch, embed, hid, ROVIT_LIN_RELU, stream));
-    RUN(rovit_linear_fwd(hidden + 2 * hs, params[10], params[11], nullptr, mu, batch, hid, 1, 0, stream));
-    RUN(rovit_linear_fwd(hidden + 2 * hs, params[12], params[13], nullptr, log_var, batch, hid, 1, ROVIT_LIN_CLAMP10, stream));
+    f2.d[n] = {hidden + 2 * hs, params[10], params[11], nullptr, mu, hid, 1, 0}; work[n++] = batch;
+    f2.d[n] = {hidden + 2 * hs, params[12], params[13], nullptr, log_var, hid, 1, ROVIT_LIN_CLAMP10}; work[n++] = batch;
   }
-  return ROVIT_OK;
+  return launch_lin_batch(f2, n, work, lin_fwd_batch_kernel, "lin_fwd_batch_kernel", (hipStream_t)stream);
 }
 
 // grads[] mirrors params[]; g_* may be NULL (head inactive or output unused); log_var is the clamped forward output.
-// scratch: (B, hid) floats.  d_features is overwritten (accumulate_dfeat == 0) or accumulated into.
+// scratch: (3, B, hid) floats.  d_features is overwritten (accumulate_dfeat == 0) or accumulated into.
 extern "C" int rovit_heads_bwd(const float* features, const float* const* params, const float* const* masks,
                                const float* hidden, const float* log_var, const float* g_cls, const float* g_ord,
                                const float* g_mu, const float* g_lv, float* d_features, float* const* grads, float* scratch,
                                int batch, int embed, int hid, int num_classes, int accumulate_dfeat, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(features && params && hidden && grads && scratch && d_features, ROVIT_ERR_NULL, "heads_bwd: null pointer");
+  ROVIT_CHECK_ARG((g_mu == nullptr) == (g_lv == nullptr), ROVIT_ERR_NULL, "heads_bwd: mu and log_var gradients come together");
+  ROVIT_CHECK_ARG(!g_lv || log_var, ROVIT_ERR_NULL, "heads_bwd: log_var output needed for the clamp gate");
   const size_t hs = (size_t)batch * hid;
-  int rc;
-  int acc = accumulate_dfeat;
-  if (g_cls) {
-    RUN(rovit_linear_bwd(hidden, params[2], g_cls, nullptr, masks ? masks[0] : nullptr, hidden, scratch, grads[2], grads[3], batch, hid, num_classes, 0, stream));
-    RUN(rovit_linear_bwd(features, params[0], scratch, nullptr, nullptr, nullptr, d_features, grads[0], grads[1], batch, embed, hid, acc, stream));
-    acc = 1;
+  hipStream_t st = (hipStream_t)stream;
+  const bool act[3] = {g_cls != nullptr, g_ord != nullptr, g_mu != nullptr};
+  // 1) dL/d(hidden) of every active head (through ReLU and the dropout mask)
+  LinDxBatch dxh{}; dxh.B = batch;
+  LinDwBatch dwo{}; dwo.B = batch;
+  int wx[4], ww[4], nx = 0, nw = 0;
+  if (act[0]) {
+    dxh.d[nx] = {1, {g_cls}, {params[2]}, {nullptr}, {num_classes}, masks ? masks[0] : nullptr, hidden, scratch, hid, 0}; wx[nx++] = batch * hid;
+    dwo.d[nw] = {g_cls, hidden, nullptr, grads[2], grads[3], hid, num_classes}; ww[nw++] = num_classes * hid;
   }
-  if (g_ord) {
-    RUN(rovit_linear_bwd(hidden + hs, params[6], g_ord, nullptr, masks ? masks[1] : nullptr, hidden + hs, scratch, grads[6], grads[7], batch, hid, num_classes - 1, 0, stream));
-    RUN(rovit_linear_bwd(features, params[4], scratch, nullptr, nullptr, nullptr, d_features, grads[4], grads[5], batch, embed, hid, acc, stream));
-    acc = 1;
+  if (act[1]) {
+    dxh.d[nx] = {1, {g_ord}, {params[6]}, {nullptr}, {num_classes - 1}, masks ? masks[1] : nullptr, hidden + hs, scratch + hs, hid, 0}; wx[nx++] = batch * hid;
+    dwo.d[nw] = {g_ord, hidden + hs, nullptr, grads[6], grads[7], hid, num_classes - 1}; ww[nw++] = (num_classes - 1) * hid;
   }
-  if (g_mu || g_lv) {
-    ROVIT_CHECK_ARG(g_mu && g_lv && log_var, ROVIT_ERR_NULL, "heads_bwd: mu and log_var gradients come together");
-    const float* m2 = masks ? masks[2] : nullptr;
-    RUN(rovit_linear_bwd(hidden + 2 * hs, params[10], g_mu, nullptr, m2, hidden + 2 * hs, scratch, grads[10], grads[11], batch, hid, 1, 0, stream));
-    RUN(rovit_linear_bwd(hidden + 2 * hs, params[12], g_lv, log_var, m2, hidden + 2 * hs, scratch, grads[12], grads[13], batch, hid, 1, 1, stream));
-    RUN(rovit_linear_bwd(features, params[8], scratch, nullptr, nullptr, nullptr, d_features, grads[8], grads[9], batch, embed, hid, acc, stream));
-    acc = 1;
+  if (act[2]) {
+    dxh.d[nx] = {2, {g_mu, g_lv}, {params[10], params[12]}, {nullptr, log_var}, {1, 1}, masks ? masks[2] : nullptr, hidden + 2 * hs,
+                 scratch + 2 * hs, hid, 0};
+    wx[nx++] = batch * hid;
+    dwo.d[nw] = {g_mu, hidden + 2 * hs, nullptr, grads[10], grads[11], hid, 1}; ww[nw++] = hid;
+    dwo.d[nw] = {g_lv, hidden + 2 * hs, log_var, grads[12], grads[13], hid, 1}; ww[nw++] = hid;
   }
-#undef RUN
-  if (!acc) {
-    hipError_t e = hipMemsetAsync(d_features, 0, (size_t)batch * embed * sizeof(float), (hipStream_t)stream);
-    ROVIT_CHECK_ARG(e == hipSuccess, ROVIT_ERR_LAUNCH, "heads_bwd: memset failed");
+  if (nx == 0) {
+    if (!accumulate_dfeat) {
+      hipError_t e = hipMemsetAsync(d_features, 0, (size_t)batch * embed * sizeof(float), st);
+      ROVIT_CHECK_ARG(e == hipSuccess, ROVIT_ERR_LAUNCH, "heads_bwd: memset failed");
+    }
+    return ROVIT_OK;
   }
-  return ROVIT_OK;
+  int rc = launch_lin_batch(dxh, nx, wx, lin_bwd_dx_batch_kernel, "lin_bwd_dx_batch_kernel", st);
+  if (rc) return rc;
+  rc = launch_lin_batch(dwo, nw, ww, lin_bwd_dw_batch_kernel, "lin_bwd_dw_batch_kernel", st);
+  if (rc) return rc;
+  // 2) through the first layers: d_features = sum_h dh_h W1_h ; dW1_h = dh_h^T features
+  LinDxBatch dxf{}; dxf.B = batch;
+  LinDwBatch dw1{}; dw1.B = batch;
+  LinDxDesc& f = dxf.d[0];
+  f = LinDxDesc{};
+  f.mul = nullptr; f.pos = nullptr; f.dx = d_features; f.in_f = embed; f.accumulate = accumulate_dfeat;
+  int n1 = 0, w1[4];
+  for (int h = 0; h < 3; ++h) {
+    if (!act[h]) continue;
+    f.g[f.nsrc] = scratch + h * hs; f.w[f.nsrc] = params[4 * h]; f.yc[f.nsrc] = nullptr; f.out_f[f.nsrc] = hid; f.nsrc++;
+    dw1.d[n1] = {scratch + h * hs, features, nullptr, grads[4 * h], grads[4 * h + 1], embed, hid}; w1[n1++] = hid * embed;
+  }
+  int wf[1] = {batch * embed};
+  rc = launch_lin_batch(dxf, 1, wf, lin_bwd_dx_batch_kernel, "lin_bwd_dx_batch_kernel", st);
+  if (rc) return rc;
+  return launch_lin_batch(dw1, n1, w1, lin_bwd_dw_batch_kernel, "lin_bwd_dw_batch_kernel", st);
 }

@@ -110,7 +110,7 @@ class HeadsFn(torch.autograd.Function):
             if live[i]:
                 grads[i] = torch.empty_like(p)
         dfeat = torch.empty_like(features)
-        scratch = torch.empty(B, hid, device=dev, dtype=torch.float32)
+        scratch = torch.empty(3, B, hid, device=dev, dtype=torch.float32)
         masks = ctx.masks
         marr = ptr_array([_f32c(m) if m is not None else None for m in masks]) if masks is not None else None
         call('rovit_heads_bwd', ptr(features), ptr_array(params), marr, ptr(hidden), ptr(lv) if lv.numel() else None,

@@ -509,6 +509,182 @@ int launch_ws(const GemmArgs& g0, int epi, hipStream_t st) {
   return ROVIT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// K = 192 weight-stationary GEMM with the A tiles brought in by LDS-DMA (global_load_lds_dwordx4) into a 3-slot
+// ring: no staging registers, so TWO 24 KB tiles per workgroup are in flight while a third is consumed.
+// (The register-staged kernel above can keep only one tile per workgroup in flight, which caps a CU at ~25 GB/s
+// of loads: its load/LDS/barrier skeleton alone costs ~16 us on the qkv shape.)
+//   * LDS-DMA writes lane-linear (wave-uniform base + 16 B x lane), so rows are unpadded 384-byte rows and the
+//     bank-conflict fix is an XOR swizzle of the 16-byte chunk index: physical chunk x of row r holds logical
+//     chunk (x & ~7) | ((x & 7) ^ ((r >> 1) & 7)); applied on the SOURCE address of the DMA and on the fragment
+//     read (conflict-free for ds_read_b128 fragment reads, checked by brute force over the b128 lane groups).
+//   * completion: a wave's vmcnt covers its own DMA pieces and its epilogue stores, in issue order.  Per tile the
+//     order is [DMA(t+2)] [stores(t)], so "tile t+1 landed" == at most SMAX + 6 younger ops outstanding.
+//   * the staged-output tile aliases the ring slot that was just consumed (same XOR idea against write conflicts).
+// Only for epilogues that issue no global LOADS inside the loop (BF16, GELU): a compiler-visible load would be
+// waited for with vmcnt(0) and drain the DMA queue.
+// ------------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_ws_dma_kernel(const GemmArgs g, int tiles_per_wg, int n_tiles_m) {
+  constexpr int KS = 6, K = 192, BM = 64, TM = 4, NT = 256;
+  constexpr int SLOT = BM * K;                              // bf16 elements per ring slot
+  constexpr int SMAX = (EPI == EPI_GELU) ? 12 : 6;          // global stores one thread issues per tile
+  extern __shared__ __attribute__((aligned(16))) bf16 lds[];   // ring[3][64][192]; ONE array (see cdna guide)
+
+  const int nchunks = g.n_tiles;
+  const int bid = blockIdx.x;
+  const int chunk = (bid >> 3) % nchunks;
+  const int p = (bid / (8 * nchunks)) * 8 + (bid & 7);
+  const int tile0 = p * tiles_per_wg;
+  int ntile = n_tiles_m - tile0;
+  ntile = ntile > tiles_per_wg ? tiles_per_wg : ntile;
+  if (ntile <= 0) return;
+  const int n0 = chunk * 192;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  // DMA pieces of this wave: piece j = wave + 4 i covers linear chunks 64 j + lane of the slot
+  int d_row[6], d_col[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int c = 64 * (wave + 4 * i) + lane;
+    const int r = c / 24, x = c - r * 24;
+    d_row[i] = r;
+    d_col[i] = ((x & ~7) | ((x & 7) ^ ((r >> 1) & 7))) * 8;
+  }
+  auto dma = [&](int tile, int slot) {
+    const int row0 = tile * BM;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      int gr = row0 + d_row[i];
+      gr = gr < g.M ? gr : g.M - 1;
+      const bf16* src = g.A + (size_t)gr * g.lda + d_col[i];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(lds + slot * SLOT + (wave + 4 * i) * 512), 16, 0, 0);
+    }
+  };
+  dma(tile0, 0);
+  if (ntile > 1) dma(tile0 + 1, 1);
+  if (ntile > 2) dma(tile0 + 2, 2);
+
+  // stationary W fragments + bias (loaded once; nothing else is loaded from global memory inside the loop)
+  bf16x8 wf[3][KS];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      wf[j][ks] = *(const bf16x8*)(g.W + (size_t)(n0 + 48 * wn + 16 * j + l15) * g.ldw + ks * 32 + lg * 8);
+  f32x4 bias4[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    bias4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (g.bias) {
+      const float4 bb = *(const float4*)(g.bias + n0 + 48 * wn + 16 * j + 4 * lg);
+      bias4[j] = (f32x4){bb.x, bb.y, bb.z, bb.w};
+    }
+  }
+  // swizzled fragment-read offsets: logical chunk 4 ks + lg of row (16 i + l15)
+  const int swz = (l15 >> 1) & 7;
+  const int xo0 = ((0 + lg) ^ swz) * 8, xo1 = ((4 + lg) ^ swz) * 8;
+  const int frag_row = l15 * K;
+  // staged-output tile (aliases the consumed slot): 8-byte write of this lane, 16-byte read-back chunks
+  const int cw_row = l15, cw_swz = l15 & 7;
+
+  for (int t = 0; t < ntile; ++t) {
+    const int slot = t % 3;
+    // tile t has landed once at most (DMA(t+1..) + this tile's predecessors' stores) are outstanding
+    if (t + 2 < ntile) {
+      if (t == 0) wait_vmcnt<12>(); else wait_vmcnt<6 + SMAX>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();                     // every wave's pieces of tile t are in; tile t-1 fully retired
+    if (t >= 1 && t + 2 < ntile) dma(tile0 + t + 2, (t + 2) % 3);     // refill the slot tile t-1 used
+
+    f32x4 acc[TM][3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i][j] = bias4[j];
+    const bf16* Ac = lds + slot * SLOT + frag_row;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 af[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(Ac + i * 16 * K + (ks >> 1) * 64 + ((ks & 1) ? xo1 : xo0));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(wf[j][ks], af[i], acc[i][j]);     // D[n][m]
+    }
+    barrier_lds();                                    // all fragment reads of this slot are done: reuse it for C
+    bf16* Cs = lds + slot * SLOT;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int ch = 6 * wn + 2 * j + (lg >> 1);
+        const int phys = (ch & ~7) | ((ch & 7) ^ cw_swz);
+        *(bf16x4*)(Cs + (i * 16 + cw_row) * K + phys * 8 + 4 * (lg & 1)) = pack4(acc[i][j]);
+      }
+    barrier_lds();
+    const int mbase = (tile0 + t) * BM;
+#pragma unroll
+    for (int q = 0; q < BM * 24 / NT; ++q) {
+      const int c = tid + q * NT;
+      const int row = c / 24, ch = c - row * 24;
+      const int m = mbase + row;
+      if (m < g.M) {
+        const int phys = (ch & ~7) | ((ch & 7) ^ (row & 7));
+        const bf16x8 pv = *(const bf16x8*)(Cs + row * K + phys * 8);
+        const size_t o = (size_t)m * g.ldo + n0 + ch * 8;
+        if (EPI == EPI_BF16) {
+          *(bf16x8*)(g.out + o) = pv;
+        } else {
+          bf16x8 av, dv;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float ga, gd;
+            gelu_and_grad((float)pv[e], ga, gd);
+            av[e] = (bf16)ga; dv[e] = (bf16)gd;
+          }
+          *(bf16x8*)(g.out + o) = av;
+          if (g.out2) *(bf16x8*)(g.out2 + o) = dv;
+        }
+      }
+    }
+    // no barrier here: the next iteration's top barrier retires this tile before its slot is refilled
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+template <int EPI>
+int launch_ws_dma(const GemmArgs& g0, hipStream_t st) {
+  GemmArgs g = g0;
+  g.n_tiles = g.N / 192;
+  constexpr int BM = 64;
+  const int tiles_m = (g.M + BM - 1) / BM;
+  int pmax = 512 / g.n_tiles;
+  pmax = pmax < 8 ? 8 : pmax / 8 * 8;
+  const int tpw = (tiles_m + pmax - 1) / pmax;
+  int P = (tiles_m + tpw - 1) / tpw;
+  P = (P + 7) / 8 * 8;
+  const size_t lds = (size_t)3 * BM * 192 * sizeof(bf16);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_ws_dma_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_ws_dma_kernel<EPI>), dim3(P * g.n_tiles), dim3(256), lds, st, g, tpw, tiles_m);
+  ROVIT_CHECK_LAUNCH("gemm_ws_dma_kernel");
+  return ROVIT_OK;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_nt(const GemmArgs& g0, int epi, hipStream_t st) {
   GemmArgs g = g0;
@@ -795,9 +971,16 @@ extern "C" int rovit_gemm_nt(const void* A, int lda, const void* W, int ldw, int
     default: ROVIT_CHECK_ARG(false, ROVIT_ERR_SHAPE, "gemm_nt: unknown epilogue %d", epi);
   }
   if (g_gemm_tile == 0 && N % 192 == 0) {
+    if (K == 192 && epi == EPI_BF16) return launch_ws_dma<EPI_BF16>(g, (hipStream_t)stream);
+    if (K == 192 && epi == EPI_GELU) return launch_ws_dma<EPI_GELU>(g, (hipStream_t)stream);
     if (K == 192) return launch_ws<6, 1, 64>(g, epi, (hipStream_t)stream);
     if (K == 576) return launch_ws<9, 2, 32>(g, epi, (hipStream_t)stream);
     if (K == 768) return launch_ws<12, 2, 32>(g, epi, (hipStream_t)stream);
+  }
+  if (g_gemm_tile == 1 && N % 192 == 0 && (K == 192 || K == 576 || K == 768)) {      // register-staged weight-stationary kernel
+    if (K == 192) return launch_ws<6, 1, 64>(g, epi, (hipStream_t)stream);
+    if (K == 576) return launch_ws<9, 2, 32>(g, epi, (hipStream_t)stream);
+    return launch_ws<12, 2, 32>(g, epi, (hipStream_t)stream);
   }
   if (g_gemm_tile <= 2 && N % 192 == 0) return launch_nt<128, 192, 2, 2>(g, epi, (hipStream_t)stream);
   return launch_nt<128, 96, 2, 2>(g, epi, (hipStream_t)stream);

@@ -96,6 +96,11 @@ size_t rovit_vit_workspace_bytes(int batch, int depth, int training);
 int rovit_vit_prepare(const float* const* params, void* prep, int depth, rovit_stream_t stream);
 int rovit_vit_forward(const float* images, const float* const* params, const void* prep, void* workspace, float* features,
                       int batch, int depth, int training, rovit_stream_t stream);
+/* forward + explainability taps: attn_taps is a HOST array of `depth` device pointers (bf16 (B*197,192)) that receive
+ * each block's attention-module output -- what DeiTTinyBackbone.get_attention_maps collects through forward hooks on
+ * `blocks[i].attn` (models/backbone.py:37-62).  Uses the inference workspace. */
+int rovit_vit_forward_taps(const float* images, const float* const* params, const void* prep, void* workspace, float* features,
+                           void* const* attn_taps, int batch, int depth, rovit_stream_t stream);
 int rovit_vit_backward(const float* d_features, const float* const* params, const void* prep, void* workspace,
                        float* const* grads, int batch, int depth, int first_block, int last_block, rovit_stream_t stream);
 
@@ -142,6 +147,15 @@ int rovit_cls_norm_bwd(const float* dfeat, const float* xhat, const float* rstd,
 int rovit_pos_grad(const float* dX, float* dpos, float* dcls, int batch, int tokens, rovit_stream_t stream);
 int rovit_prep_weight(const float* W, const float* bias, const float* gamma, const float* beta, void* Wf, void* WfT,
                       float* bias_f, int N, int K, rovit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Batch augmentation on the device: the data movement of `cutmix_or_mixup` (call site training/trainer.py:84-96;
+ * its module data/transforms.py is absent from the reference checkout, so this follows the published MixUp / CutMix
+ * definitions).  mode 0: out[b] = lam x[b] + (1-lam) x[perm[b]];  mode 1: out[b] = x[perm[b]] inside rows [y0,y1) x
+ * cols [x0,x1), x[b] elsewhere.  images/out fp32 (B,C,H,W) distinct buffers, perm int64 (B) on the device.
+ * ------------------------------------------------------------------------------------------------------------ */
+int rovit_mix_images(const float* images, float* out, const long long* perm, int batch, int channels, int height, int width,
+                     int mode, float lam, int y0, int y1, int x0, int x1, rovit_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Optimizer step on flat fp32 buffers: global-norm clipping + AdamW as the reference applies them

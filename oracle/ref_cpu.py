@@ -263,7 +263,7 @@ def init_vit_state(depth: int = VIT_DEPTH, generator: Optional[torch.Generator] 
 
 
 def vit_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str = '', heads: int = VIT_HEADS,
-                eps: float = 1e-6, return_tokens: bool = False):
+                eps: float = 1e-6, return_tokens: bool = False, attn_taps: Optional[list] = None):
     """timm VisionTransformer.forward for deit_tiny_patch16_224, num_classes=0:
     patch conv k16/s16 -> [cls | patches] + pos_embed -> 12 pre-norm blocks -> LayerNorm -> token 0."""
     B = x.shape[0]
@@ -281,7 +281,10 @@ def vit_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str = '', 
         q, k, v = qkv[0], qkv[1], qkv[2]
         a = torch.softmax((q * hd ** -0.5) @ k.transpose(-2, -1), dim=-1)
         o = (a @ v).transpose(1, 2).reshape(B, -1, dim)
-        t = t + F.linear(o, sd[b + 'attn.proj.weight'], sd[b + 'attn.proj.bias'])
+        ao = F.linear(o, sd[b + 'attn.proj.weight'], sd[b + 'attn.proj.bias'])
+        if attn_taps is not None:                                      # what a forward hook on blocks[i].attn sees
+            attn_taps.append(ao)                                       # (reference models/backbone.py:37-62)
+        t = t + ao
         h = F.layer_norm(t, (dim,), sd[b + 'norm2.weight'], sd[b + 'norm2.bias'], eps)
         h = F.gelu(F.linear(h, sd[b + 'mlp.fc1.weight'], sd[b + 'mlp.fc1.bias']))
         t = t + F.linear(h, sd[b + 'mlp.fc2.weight'], sd[b + 'mlp.fc2.bias'])

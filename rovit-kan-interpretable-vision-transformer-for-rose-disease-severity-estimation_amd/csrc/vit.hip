@@ -142,9 +142,9 @@ extern "C" int rovit_vit_prepare(const float* const* params, void* prep, int dep
   return ROVIT_OK;
 }
 
-// images fp32 NCHW (B,3,224,224) -> features fp32 (B,192)
-extern "C" int rovit_vit_forward(const float* images, const float* const* params, const void* prep, void* workspace,
-                                 float* features, int batch, int depth, int training, rovit_stream_t stream) {
+namespace {
+int vit_forward_impl(const float* images, const float* const* params, const void* prep, void* workspace, float* features,
+                     void* const* attn_taps, int batch, int depth, int training, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(images && features, ROVIT_ERR_NULL, "vit_forward: null images/features");
   RUN(check_common(params, prep, workspace, batch, depth));
   const Prep P(depth);
@@ -172,6 +172,11 @@ extern "C" int rovit_vit_forward(const float* images, const float* const* params
     // attention is row-wise: run proj / LN2 / MLP of that block on the B CLS rows only (row step T).
     const bool cls_only = (i == depth - 1);
     const int Mr = cls_only ? batch : M, rs = cls_only ? T : 1;
+    // explainability tap: the attention module's output (proj(attention) + bias, before the residual add) for
+    // every token of block i -- what a forward hook on `blocks[i].attn` sees (reference models/backbone.py:37-62)
+    if (attn_taps && attn_taps[i])
+      RUN(rovit_gemm_nt(s + L.o, D, q + P.wproj, D, M, D, D, bp[B_PROJB], EPI_BF16, attn_taps[i], D, nullptr, nullptr, 0, nullptr, 0,
+                        nullptr, 0, stream));
     if (cls_only) {
       RUN(rovit_gemm_nt(s + L.o, D * rs, q + P.wproj, D, Mr, D, D, bp[B_PROJB], EPI_RESID, nullptr, 0, nullptr, X, D * rs, nullptr, 0,
                         nullptr, 0, stream));
@@ -192,6 +197,21 @@ extern "C" int rovit_vit_forward(const float* images, const float* const* params
   RUN(rovit_cls_norm_fwd(X, params[P_NORM_W], params[P_NORM_B], features, (float*)(ws + L.xhat_cls), (float*)(ws + L.rstd_cls), batch,
                          T, eps, stream));
   return ROVIT_OK;
+}
+}  // namespace
+
+// images fp32 NCHW (B,3,224,224) -> features fp32 (B,192)
+extern "C" int rovit_vit_forward(const float* images, const float* const* params, const void* prep, void* workspace,
+                                 float* features, int batch, int depth, int training, rovit_stream_t stream) {
+  return vit_forward_impl(images, params, prep, workspace, features, nullptr, batch, depth, training, stream);
+}
+
+// Same forward (inference workspace), additionally writing each block's attention-module output into
+// attn_taps[i] (bf16, (B*197,192)); NULL entries are skipped.
+extern "C" int rovit_vit_forward_taps(const float* images, const float* const* params, const void* prep, void* workspace,
+                                      float* features, void* const* attn_taps, int batch, int depth, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(attn_taps, ROVIT_ERR_NULL, "vit_forward_taps: null tap array");
+  return vit_forward_impl(images, params, prep, workspace, features, attn_taps, batch, depth, 0, stream);
 }
 
 // Backward over blocks first_block, first_block-1, ..., last_block (inclusive).  first_block == depth-1 also

@@ -34,6 +34,7 @@ SIGNATURES = {
     'rovit_vit_workspace_bytes': (_sz, [_i, _i, _i]),
     'rovit_vit_prepare': (_i, [_vp, _vp, _i, _vp]),
     'rovit_vit_forward': (_i, [_vp] * 5 + [_i] * 3 + [_vp]),
+    'rovit_vit_forward_taps': (_i, [_vp] * 6 + [_i, _i, _vp]),
     'rovit_vit_backward': (_i, [_vp] * 5 + [_i] * 4 + [_vp]),
     'rovit_gemm_nt': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     'rovit_gemm_resid_ln': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp]),
@@ -57,6 +58,7 @@ SIGNATURES = {
     'rovit_joint_loss': (_i, [_vp] * 14 + [_i, _i, _f, _f, _f, _f, _vp]),
     'rovit_scale_buffers': (_i, [_vp, _vp, _i, _vp, _vp]),
     'rovit_sq_norm_accum': (_i, [_vp, _sz, _vp, _vp]),
+    'rovit_mix_images': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp]),
     'rovit_adamw_flat': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _i, _vp]),
 }
 

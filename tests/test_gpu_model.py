@@ -228,3 +228,80 @@ def test_flat_adamw_matches_torch_clip_and_adamw():
         upd = float((p2.detach() - before[n2]).abs().max())
         assert upd > 0, n1
         assert float((p1.detach() - p2.detach()).abs().max()) < 2e-3 * upd + 1e-9, n1
+
+
+@pytest.mark.parametrize('B', [1, 3, 17])
+def test_inference_workspace_equals_training_forward_ragged_batches(B):
+    """no_grad forward (activation buffers shared by all blocks) == grad-mode forward (per-block buffers), for batch
+    sizes whose row counts are not multiples of any tile size (M = 197, 591, 3349)."""
+    sd = ref_cpu.init_vit_state(12, torch.Generator().manual_seed(8))
+    m = _vit(12, sd)
+    x = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(B)).to(dev())
+    with torch.no_grad():
+        f_inf = m(x).clone()
+    f_trn = m(x)
+    assert f_trn.requires_grad and not f_inf.requires_grad
+    assert torch.equal(f_inf, f_trn.detach())
+    with torch.no_grad():
+        ref = ref_cpu.vit_forward(x.cpu(), sd)
+    assert float((f_inf.cpu() - ref).abs().max()) < BF16_TOL
+    f_trn.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_forward_is_deterministic_and_batch_independent():
+    """same image -> same features whatever the batch it sits in (no cross-sample coupling, no atomics in forward)."""
+    sd = ref_cpu.init_vit_state(12, torch.Generator().manual_seed(9))
+    m = _vit(12, sd)
+    x = torch.randn(6, 3, 224, 224, generator=torch.Generator().manual_seed(1)).to(dev())
+    with torch.no_grad():
+        a = m(x).clone()
+        b = m(x).clone()
+        c = m(x[2:4]).clone()
+    assert torch.equal(a, b)
+    assert torch.equal(a[2:4], c)
+
+
+def test_backward_is_deterministic():
+    sd = ref_cpu.init_vit_state(2, torch.Generator().manual_seed(10))
+    m = _vit(2, sd)
+    x = torch.randn(5, 3, 224, 224, generator=torch.Generator().manual_seed(2)).to(dev())
+    grads = []
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad = None
+        m(x).square().sum().backward()
+        grads.append([p.grad.clone() for p in m.parameters()])
+    for g0, g1, (n, _) in zip(grads[0], grads[1], m.named_parameters()):
+        if n.endswith('norm1.weight') or n.endswith('norm1.bias') or n.endswith('norm2.weight') or n.endswith('norm2.bias'):
+            assert float((g0 - g1).abs().max()) <= 1e-5 * float(g0.abs().max() + 1e-12), n    # 8-way float atomics
+        else:
+            assert torch.equal(g0, g1), n                                                     # slab reductions: bitwise
+
+
+def test_attention_output_taps_vs_oracle():
+    """DeiTTinyBackbone.get_attention_maps (reference models/backbone.py:37-62): per-block attention-module outputs.
+    The oracle collects the same tensors; tolerance is the bf16 one relative to each tap's scale (taps are stored in
+    bf16 and are O(0.1) at init scale)."""
+    from models.backbone import DeiTTinyBackbone
+    depth, B = 12, 3
+    gen = torch.Generator().manual_seed(31)
+    sd = ref_cpu.init_vit_state(depth, gen)
+    x = torch.randn(B, 3, 224, 224, generator=gen)
+    ref_taps = []
+    with torch.no_grad():
+        ref_f = ref_cpu.vit_forward(x, sd, attn_taps=ref_taps)
+    bb = DeiTTinyBackbone(pretrained=False)
+    bb.model.load_state_dict(sd)
+    bb = bb.to(dev())
+    with torch.no_grad():
+        f_plain = bb(x.to(dev()))
+    taps = bb.get_attention_maps(x.to(dev()))
+    assert len(taps) == depth and all(t.shape == (B, 197, 192) and t.dtype == torch.float32 for t in taps)
+    for i, (t, r) in enumerate(zip(taps, ref_taps)):
+        scale = float(r.abs().max())
+        err = float((t.cpu() - r).abs().max())
+        assert err < BF16_TOL * max(scale, 1.0) and err < 0.1 * scale + 1e-3, (i, err, scale)
+    with torch.no_grad():                                             # tapping does not disturb the plain forward
+        assert torch.equal(bb(x.to(dev())), f_plain)
+    assert float((f_plain.cpu() - ref_f).abs().max()) < BF16_TOL

@@ -10,6 +10,7 @@
 //   attention out bf16 (M,192) + lse2 (B,3,T), act = gelu(pre) and dact = gelu'(pre) bf16 (M,768)
 //   LayerNorm affines are folded into the following Linear (W*gamma, b + W beta) by rovit_vit_prepare, so the
 //   GEMM operand is the normalised xhat itself and the wgrad recovers dgamma/dbeta from G = dY^T xhat.
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -55,7 +56,7 @@ struct Plan {          // byte offsets into the workspace
   size_t blk0, blk_stride;
   size_t xhat1, rstd1, qkv, lse, o, xhat2, rstd2, act, dact;   // inside one block
   // backward temporaries
-  size_t dX, dXb, dpre, dxhat, dO, dqkv;
+  size_t dX, x0[3], x1[2], dpre[2], dxhat, dO, dqkv[2];     // rotating buffers of the two-stream backward (see rovit_vit_backward)
   size_t slab_qkv, slab_proj, slab_fc1, slab_fc2, slab_pe, gscr, gscr2;
   int s_qkv, s_proj, s_fc1, s_fc2, s_pe;
   int s_projc, s_fc1c, s_fc2c;      // split counts when only the B CLS rows are processed (last block)
@@ -89,11 +90,12 @@ struct Plan {          // byte offsets into the workspace
     s_fc2c = rovit_wgrad_splits(B, D, MLP);
     if (training) {
       dX = o; o = al(o + M * D * 4);
-      dXb = o; o = al(o + M * D * 2);
-      dpre = o; o = al(o + M * MLP * 2);
+      for (int k = 0; k < 3; ++k) { x0[k] = o; o = al(o + M * D * 2); }
+      for (int k = 0; k < 2; ++k) { x1[k] = o; o = al(o + M * D * 2); }
+      for (int k = 0; k < 2; ++k) { dpre[k] = o; o = al(o + M * MLP * 2); }
       dxhat = o; o = al(o + M * D * 2);
       dO = o; o = al(o + M * D * 2);
-      dqkv = o; o = al(o + M * 3 * D * 2);
+      for (int k = 0; k < 2; ++k) { dqkv[k] = o; o = al(o + M * 3 * D * 2); }
       slab_qkv = o; o = al(o + rovit_wgrad_workspace_bytes(3 * D, D, s_qkv));
       slab_proj = o; o = al(o + rovit_wgrad_workspace_bytes(D, D, s_proj));
       slab_fc1 = o; o = al(o + rovit_wgrad_workspace_bytes(MLP, D, s_fc1));
@@ -107,6 +109,46 @@ struct Plan {          // byte offsets into the workspace
 };
 
 #define RUN(call) do { int rc__ = (call); if (rc__ != ROVIT_OK) return rc__; } while (0)
+
+// ---- second stream for the weight-gradient kernels of the backward pass -------------------------------------
+// Every kernel here is a short persistent launch (20-60 us) whose ramp (dispatch, W-fragment prologue, first tile,
+// tail) is ~6 us of it.  The dgrad chain (stream A = the caller's) and the wgrad/reduce kernels (stream B) of a
+// block are independent given the activations, so running them on two HIP streams lets one kernel's ramp and tail
+// be covered by the other's steady state.  Buffers the two streams hand over (dXb, dpre, dqkv) are double-buffered
+// and every hand-over is an event; B is joined back into A before rovit_vit_backward returns.
+struct SideStream {
+  hipStream_t stream = nullptr;
+  std::vector<hipEvent_t> events;
+  size_t next = 0;
+  hipEvent_t get() {
+    if (next == events.size()) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return nullptr;
+      events.push_back(e);
+    }
+    return events[next++];
+  }
+};
+SideStream* side_stream() {
+  static SideStream per_dev[64];
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
+  SideStream& s = per_dev[d];
+  if (!s.stream && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  return &s;
+}
+// record an event on `from` and make `to` wait for it; returns the event (or nullptr on failure)
+hipEvent_t hand_over(SideStream* ss, hipStream_t from, hipStream_t to) {
+  hipEvent_t e = ss->get();
+  if (!e || hipEventRecord(e, from) != hipSuccess) return nullptr;
+  if (to && hipStreamWaitEvent(to, e, 0) != hipSuccess) return nullptr;
+  return e;
+}
+// ROVIT_SINGLE_STREAM=1 keeps the whole backward on the caller's stream (debugging / A-B timing)
+bool two_streams_enabled() {
+  static const bool on = [] { const char* e = getenv("ROVIT_SINGLE_STREAM"); return !(e && e[0] == '1'); }();
+  return on;
+}
 
 int check_common(const void* params, const void* prep, const void* ws, int batch, int depth) {
   ROVIT_CHECK_ARG(params && prep && ws, ROVIT_ERR_NULL, "vit: null params/prep/workspace");
@@ -231,46 +273,34 @@ extern "C" int rovit_vit_backward(const float* d_features, const float* const* p
   char* ws = (char*)workspace;
   const int M = (int)L.M;
   float* dX = (float*)(ws + L.dX);
-  char* dXb = ws + L.dXb;
+  // bf16 copy of the residual-stream gradient ENTERING block i lives in x0[i % 3] (x0v(-1) feeds the patch embedding)
+  auto x0v = [&](int i) { return ws + L.x0[(i + 3) % 3]; };
   if (first_block == depth - 1) {
     ROVIT_CHECK_ARG(d_features, ROVIT_ERR_NULL, "vit_backward: null d_features");
-    RUN(rovit_cls_norm_bwd(d_features, (const float*)(ws + L.xhat_cls), (const float*)(ws + L.rstd_cls), params[P_NORM_W], dX, dXb,
-                           grads[P_NORM_W], grads[P_NORM_B], batch, T, stream));
+    RUN(rovit_cls_norm_bwd(d_features, (const float*)(ws + L.xhat_cls), (const float*)(ws + L.rstd_cls), params[P_NORM_W], dX,
+                           x0v(depth - 1), grads[P_NORM_W], grads[P_NORM_B], batch, T, stream));
   }
-  for (int i = first_block; i >= last_block; --i) {
+  // Two-stream schedule (see SideStream above).  Per block i (p = i & 1), stream A runs the dgrad chain
+  //   A1 fc2 dgrad * gelu' : x0[i%3] -> dpre[p]        A2 fc1 dgrad + norm2 bwd : dpre[p] -> dX, x1[p]
+  //   A3 proj dgrad : x1[p] -> dO                       A4 attention bwd : dO -> dqkv[p]
+  //   A5 qkv dgrad + norm1 bwd : dqkv[p] -> dX, x0[(i-1)%3]
+  // and stream B the weight gradients  B1 fc2 (x0[i%3], act)  B2 fc1 (dpre[p], xhat2)  B3 proj (x1[p], o)
+  //   B4 qkv (dqkv[p], xhat1)  B5 slab reduction -> grads.
+  // Events cost ~6 us of idle time on the stream that records or waits, so A does ONE record per block (E_i, after
+  // A2) and ONE wait (for B5 of block i+2, long finished): B issues [B4 B5](i+1) [B1 B2 B3](i) behind E_i.  The
+  // rotating buffers make that safe: a buffer written by A in block i was last read by B in block i+2 (x1, dpre,
+  // dqkv: parity pairs) or i+3 (x0: three buffers, A5 of block i overwrites what B1 of block i+2 read).
+  hipStream_t sA = (hipStream_t)stream;
+  SideStream* ss = two_streams_enabled() ? side_stream() : nullptr;
+  hipStream_t sB = ss ? ss->stream : sA;
+  if (ss) ss->next = 0;
+  hipEvent_t ev_bdone[64] = {};
+  int pending = -1;                                   // block whose B4/B5 have not been issued yet
+#define EVFAIL(what) do { rovit_set_error("vit_backward: " what " failed"); return ROVIT_ERR_LAUNCH; } while (0)
+  auto reduce_block = [&](int i, bool cls_only, rovit_stream_t st) -> int {
     const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
     float* const* bg = grads + P_BLOCK0 + B_COUNT * i;
-    const char* q = pb + P.blk0 + (size_t)i * P.blk_stride;
-    char* s = ws + L.blk0 + (size_t)i * L.blk_stride;
-    // the last block's post-attention half only ever sees gradient on the B CLS rows (see rovit_vit_forward)
-    const bool cls_only = (i == depth - 1);
-    const int Mr = cls_only ? batch : M, rs = cls_only ? T : 1;
     const int s_fc2 = cls_only ? L.s_fc2c : L.s_fc2, s_fc1 = cls_only ? L.s_fc1c : L.s_fc1, s_proj = cls_only ? L.s_projc : L.s_proj;
-    // ---- MLP ----
-    RUN(rovit_gemm_nt(dXb, D * rs, q + P.wfc2T, D, Mr, MLP, D, nullptr, EPI_MUL, ws + L.dpre, MLP * rs, nullptr, nullptr, 0, s + L.dact,
-                      MLP * rs, nullptr, 0, stream));
-    RUN(rovit_wgrad(dXb, D * rs, s + L.act, MLP * rs, Mr, D, MLP, s_fc2, 0, (float*)(ws + L.slab_fc2), stream));
-    if (cls_only) {
-      RUN(rovit_gemm_nt(ws + L.dpre, MLP * rs, q + P.wfc1T, MLP, Mr, D, MLP, nullptr, EPI_BF16, ws + L.dxhat, D * rs, nullptr, nullptr, 0,
-                        nullptr, 0, nullptr, 0, stream));
-      RUN(rovit_wgrad(ws + L.dpre, MLP * rs, s + L.xhat2, D * rs, Mr, MLP, D, s_fc1, 0, (float*)(ws + L.slab_fc1), stream));
-      RUN(rovit_layernorm_bwd_rows(ws + L.dxhat, s + L.xhat2, (const float*)(s + L.rstd2), dX, dXb, batch, T, stream));
-      // attention backward reads dO for every query: rows other than CLS carry no gradient
-      ROVIT_CHECK_ARG(hipMemsetAsync(ws + L.dO, 0, (size_t)M * D * sizeof(bf16), (hipStream_t)stream) == hipSuccess, ROVIT_ERR_LAUNCH,
-                      "vit_backward: memset failed");
-    } else {
-      // fc1 dgrad fused with the backward of norm2 (updates dX / dXb in place)
-      RUN(rovit_gemm_ln_bwd(ws + L.dpre, MLP, q + P.wfc1T, MLP, M, MLP, s + L.xhat2, (const float*)(s + L.rstd2), dX, dXb, stream));
-      RUN(rovit_wgrad(ws + L.dpre, MLP, s + L.xhat2, D, M, MLP, D, s_fc1, 0, (float*)(ws + L.slab_fc1), stream));
-    }
-    // ---- attention ----
-    RUN(rovit_gemm_nt(dXb, D * rs, q + P.wprojT, D, Mr, D, D, nullptr, EPI_BF16, ws + L.dO, D * rs, nullptr, nullptr, 0, nullptr, 0, nullptr,
-                      0, stream));
-    RUN(rovit_wgrad(dXb, D * rs, s + L.o, D * rs, Mr, D, D, s_proj, 0, (float*)(ws + L.slab_proj), stream));
-    RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, ws + L.dqkv, batch, T, H, D / H, 0.125f, stream));
-    // qkv dgrad fused with the backward of norm1
-    RUN(rovit_gemm_ln_bwd(ws + L.dqkv, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), dX, dXb, stream));
-    RUN(rovit_wgrad(ws + L.dqkv, 3 * D, s + L.xhat1, D, M, 3 * D, D, L.s_qkv, 0, (float*)(ws + L.slab_qkv), stream));
     const RovitReduceDesc rd[4] = {
         {(const float*)(ws + L.slab_fc2), s_fc2, D, MLP, nullptr, nullptr, nullptr, bg[B_FC2W], bg[B_FC2B], nullptr, nullptr, nullptr},
         {(const float*)(ws + L.slab_fc1), s_fc1, MLP, D, bp[B_N2W], bp[B_N2B], bp[B_FC1W], bg[B_FC1W], bg[B_FC1B], bg[B_N2W], bg[B_N2B],
@@ -278,10 +308,74 @@ extern "C" int rovit_vit_backward(const float* d_features, const float* const* p
         {(const float*)(ws + L.slab_proj), s_proj, D, D, nullptr, nullptr, nullptr, bg[B_PROJW], bg[B_PROJB], nullptr, nullptr, nullptr},
         {(const float*)(ws + L.slab_qkv), L.s_qkv, 3 * D, D, bp[B_N1W], bp[B_N1B], bp[B_QKVW], bg[B_QKVW], bg[B_QKVB], bg[B_N1W], bg[B_N1B],
          (float*)(ws + L.gscr2)}};
-    RUN(rovit_wgrad_reduce_batch(rd, 4, stream));
+    return rovit_wgrad_reduce_batch(rd, 4, st);
+  };
+  auto issue_b45 = [&](int i) -> int {                 // B4 + B5 of block i (stream B already waits for A5 of block i)
+    char* s = ws + L.blk0 + (size_t)i * L.blk_stride;
+    RUN(rovit_wgrad(ws + L.dqkv[i & 1], 3 * D, s + L.xhat1, D, M, 3 * D, D, L.s_qkv, 0, (float*)(ws + L.slab_qkv), sB));
+    RUN(reduce_block(i, false, sB));
+    if (ss && !(ev_bdone[i] = hand_over(ss, sB, nullptr))) EVFAIL("event record");
+    return ROVIT_OK;
+  };
+  for (int i = first_block; i >= last_block; --i) {
+    const char* q = pb + P.blk0 + (size_t)i * P.blk_stride;
+    char* s = ws + L.blk0 + (size_t)i * L.blk_stride;
+    char* xin = x0v(i);
+    char* xout = x0v(i - 1);
+    // the last block's post-attention half only ever sees gradient on the B CLS rows (see rovit_vit_forward)
+    if (i == depth - 1) {
+      // small and serial: everything on stream A; the attention-half gradient is updated in place in xin (CLS rows)
+      const int Mr = batch, rs = T;
+      char* dp = ws + L.dpre[0];
+      char* dq = ws + L.dqkv[0];
+      RUN(rovit_gemm_nt(xin, D * rs, q + P.wfc2T, D, Mr, MLP, D, nullptr, EPI_MUL, dp, MLP * rs, nullptr, nullptr, 0, s + L.dact,
+                        MLP * rs, nullptr, 0, stream));
+      RUN(rovit_wgrad(xin, D * rs, s + L.act, MLP * rs, Mr, D, MLP, L.s_fc2c, 0, (float*)(ws + L.slab_fc2), stream));
+      RUN(rovit_gemm_nt(dp, MLP * rs, q + P.wfc1T, MLP, Mr, D, MLP, nullptr, EPI_BF16, ws + L.dxhat, D * rs, nullptr, nullptr, 0, nullptr, 0,
+                        nullptr, 0, stream));
+      RUN(rovit_wgrad(dp, MLP * rs, s + L.xhat2, D * rs, Mr, MLP, D, L.s_fc1c, 0, (float*)(ws + L.slab_fc1), stream));
+      RUN(rovit_layernorm_bwd_rows(ws + L.dxhat, s + L.xhat2, (const float*)(s + L.rstd2), dX, xin, batch, T, stream));
+      // attention backward reads dO for every query: rows other than CLS carry no gradient
+      ROVIT_CHECK_ARG(hipMemsetAsync(ws + L.dO, 0, (size_t)M * D * sizeof(bf16), sA) == hipSuccess, ROVIT_ERR_LAUNCH,
+                      "vit_backward: memset failed");
+      RUN(rovit_gemm_nt(xin, D * rs, q + P.wprojT, D, Mr, D, D, nullptr, EPI_BF16, ws + L.dO, D * rs, nullptr, nullptr, 0, nullptr, 0, nullptr,
+                        0, stream));
+      RUN(rovit_wgrad(xin, D * rs, s + L.o, D * rs, Mr, D, D, L.s_projc, 0, (float*)(ws + L.slab_proj), stream));
+      RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, dq, batch, T, H, D / H, 0.125f, stream));
+      RUN(rovit_gemm_ln_bwd(dq, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), dX, xout, stream));
+      RUN(rovit_wgrad(dq, 3 * D, s + L.xhat1, D, M, 3 * D, D, L.s_qkv, 0, (float*)(ws + L.slab_qkv), stream));
+      RUN(reduce_block(i, true, stream));
+      continue;
+    }
+    const int p = i & 1;
+    char* dp = ws + L.dpre[p];
+    char* dq = ws + L.dqkv[p];
+    char* xmid = ws + L.x1[p];
+    if (ss && i + 2 < depth && ev_bdone[i + 2] && hipStreamWaitEvent(sA, ev_bdone[i + 2], 0) != hipSuccess) EVFAIL("event wait");
+    RUN(rovit_gemm_nt(xin, D, q + P.wfc2T, D, M, MLP, D, nullptr, EPI_MUL, dp, MLP, nullptr, nullptr, 0, s + L.dact, MLP, nullptr, 0,
+                      sA));                                                                                          // A1
+    // fc1 dgrad fused with the backward of norm2 (updates dX, writes its bf16 copy)
+    RUN(rovit_gemm_ln_bwd(dp, MLP, q + P.wfc1T, MLP, M, MLP, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmid, sA));            // A2
+    if (ss && !hand_over(ss, sA, sB)) EVFAIL("event hand-over");                                                   // E_i
+    if (pending >= 0) RUN(issue_b45(pending));
+    RUN(rovit_wgrad(xin, D, s + L.act, MLP, M, D, MLP, L.s_fc2, 0, (float*)(ws + L.slab_fc2), sB));                // B1
+    RUN(rovit_wgrad(dp, MLP, s + L.xhat2, D, M, MLP, D, L.s_fc1, 0, (float*)(ws + L.slab_fc1), sB));               // B2
+    RUN(rovit_wgrad(xmid, D, s + L.o, D, M, D, D, L.s_proj, 0, (float*)(ws + L.slab_proj), sB));                   // B3
+    RUN(rovit_gemm_nt(xmid, D, q + P.wprojT, D, M, D, D, nullptr, EPI_BF16, ws + L.dO, D, nullptr, nullptr, 0, nullptr, 0, nullptr, 0,
+                      sA));                                                                                          // A3
+    RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, dq, batch, T, H, D / H, 0.125f, sA));       // A4
+    // qkv dgrad fused with the backward of norm1
+    RUN(rovit_gemm_ln_bwd(dq, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), dX, xout, sA));      // A5
+    pending = i;
   }
+  if (pending >= 0) {
+    if (ss && !hand_over(ss, sA, sB)) EVFAIL("event hand-over");
+    RUN(issue_b45(pending));
+    if (ss && !hand_over(ss, sB, sA)) EVFAIL("event hand-over");       // join: the gradients of the range are final on A
+  }
+#undef EVFAIL
   if (last_block == 0) {
-    RUN(rovit_wgrad(dXb, D, ws + L.col, PD, batch * (T - 1), D, PD, L.s_pe, T, (float*)(ws + L.slab_pe), stream));
+    RUN(rovit_wgrad(x0v(-1), D, ws + L.col, PD, batch * (T - 1), D, PD, L.s_pe, T, (float*)(ws + L.slab_pe), stream));
     RUN(rovit_wgrad_reduce((const float*)(ws + L.slab_pe), L.s_pe, D, PD, nullptr, nullptr, nullptr, grads[P_PATCH_W], grads[P_PATCH_B],
                            nullptr, nullptr, nullptr, stream));
     RUN(rovit_pos_grad(dX, grads[P_POS], grads[P_CLS], batch, T, stream));

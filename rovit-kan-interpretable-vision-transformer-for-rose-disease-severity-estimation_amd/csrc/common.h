@@ -122,6 +122,7 @@ constexpr int ROVIT_PREP_BATCH = 24;
 int rovit_prep_weight_batch(const RovitPrepDesc* descs, int n, rovit_stream_t stream);
 
 // LayerNorm forward / backward on every row_step-th row of the dense (rows*row_step, 192) buffers, in place
+void rovit_set_cu_budget(int cus);   // gemm.hip: CUs the weight-stationary GEMM launches size their grids for
 int rovit_layernorm_fwd_rows(const float* x, void* xhat, float* rstd, int rows, int row_step, float eps, rovit_stream_t stream);
 int rovit_layernorm_bwd_rows(const void* dxhat, const void* xhat, const float* rstd, float* dX, void* dXb, int rows, int row_step,
                              rovit_stream_t stream);

@@ -476,13 +476,17 @@ __global__ __launch_bounds__(256 * WK, 2) void gemm_ws_kernel(const GemmArgs g, 
   }
 }
 
+// CUs a weight-stationary launch sizes its grid for (256 = the whole chip).  The two-stream forward halves it so that
+// the kernels of the two half-batch chains co-reside instead of queueing behind each other.
+static int g_cu_budget = 256;
+
 template <int KS, int WK, int BM>
 int launch_ws(const GemmArgs& g0, int epi, hipStream_t st) {
   GemmArgs g = g0;
   g.n_tiles = g.N / 192;                                   // column chunks
   const int tiles_m = (g.M + BM - 1) / BM;
   const int wg_per_cu = WK == 1 ? 2 : 1;
-  int pmax = (256 * wg_per_cu) / g.n_tiles;
+  int pmax = (g_cu_budget * wg_per_cu) / g.n_tiles;
   pmax = pmax < 8 ? 8 : pmax / 8 * 8;
   int tpw = (tiles_m + pmax - 1) / pmax;                   // tiles per workgroup
   int P = (tiles_m + tpw - 1) / tpw;
@@ -675,7 +679,7 @@ int launch_ws_dma(const GemmArgs& g0, hipStream_t st) {
   g.n_tiles = g.N / 192;
   constexpr int BM = 64;
   const int tiles_m = (g.M + BM - 1) / BM;
-  int pmax = 512 / g.n_tiles;
+  int pmax = 2 * g_cu_budget / g.n_tiles;
   pmax = pmax < 8 ? 8 : pmax / 8 * 8;
   const int tpw = (tiles_m + pmax - 1) / pmax;
   int P = (tiles_m + tpw - 1) / tpw;
@@ -954,6 +958,7 @@ __global__ __launch_bounds__(256) void wgrad_affine_batch_kernel(const ReduceBat
 
 static int g_gemm_dbg = 0;
 extern "C" int rovit_set_gemm_debug(int d) { g_gemm_dbg = d; return ROVIT_OK; }
+void rovit_set_cu_budget(int cus) { g_cu_budget = cus < 8 ? 8 : (cus > 256 ? 256 : cus); }
 static int g_gemm_tile = 0;      // 0: weight-stationary kernel where it applies, 2: tiled 128x192, 3: tiled 128x96
 extern "C" int rovit_set_gemm_tile(int t) { g_gemm_tile = t; return ROVIT_OK; }
 

@@ -137,11 +137,12 @@ SideStream* side_stream() {
   if (!s.stream && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
   return &s;
 }
-// record an event on `from` and make `to` wait for it; returns the event (or nullptr on failure)
-hipEvent_t hand_over(SideStream* ss, hipStream_t from, hipStream_t to) {
+// record an event on `from` and (unless record_only) make `to` wait for it; returns the event (nullptr on failure).
+// NB: the caller's stream is usually the NULL stream (torch's default), so a null `to` is a real stream here.
+hipEvent_t hand_over(SideStream* ss, hipStream_t from, hipStream_t to, bool record_only = false) {
   hipEvent_t e = ss->get();
   if (!e || hipEventRecord(e, from) != hipSuccess) return nullptr;
-  if (to && hipStreamWaitEvent(to, e, 0) != hipSuccess) return nullptr;
+  if (!record_only && hipStreamWaitEvent(to, e, 0) != hipSuccess) return nullptr;
   return e;
 }
 // ROVIT_SINGLE_STREAM=1 keeps the whole backward on the caller's stream (debugging / A-B timing)
@@ -200,42 +201,89 @@ int vit_forward_impl(const float* images, const float* const* params, const void
   RUN(rovit_cls_rows(params[P_CLS], params[P_POS], X, batch, T, stream));
   RUN(rovit_gemm_nt(ws + L.col, PD, pb + P.wpe, PD, batch * (T - 1), D, PD, params[P_PATCH_B], EPI_PATCH, nullptr, 0, nullptr, X, D,
                     nullptr, 0, params[P_POS], T, stream));
+  // Samples are independent in the forward pass, so the batch is cut into two halves that run the same kernel
+  // chain on two HIP streams with no synchronisation until the final norm: every kernel here is a 20-50 us
+  // persistent launch with ~6 us of ramp (dispatch, weight prologue, first tile, tail), which the other half's
+  // kernels now cover.  Each half asks for half of the CUs (rovit_set_cu_budget) so the two chains co-reside.
+  static const bool fwd_split = !getenv("ROVIT_FWD_SINGLE");
+  SideStream* ss = (two_streams_enabled() && fwd_split && !attn_taps && batch >= 16) ? side_stream() : nullptr;
+  struct Half { int b0, nb; rovit_stream_t st; };
+  Half halves[2] = {{0, ss ? (batch + 1) / 2 : batch, stream}, {(batch + 1) / 2, ss ? batch / 2 : 0, ss ? (rovit_stream_t)ss->stream : stream}};
+  if (ss && getenv("ROVIT_DBG_SAME_STREAM")) halves[1].st = stream;
+  const int nh = ss ? 2 : 1;
+  if (ss) {
+    ss->next = 0;
+    if (!hand_over(ss, (hipStream_t)stream, ss->stream)) { rovit_set_error("vit_forward: event hand-over failed"); return ROVIT_ERR_LAUNCH; }
+    static const int budget = getenv("ROVIT_FWD_BUDGET") ? atoi(getenv("ROVIT_FWD_BUDGET")) : 128;
+    rovit_set_cu_budget(budget);
+  }
+  struct BudgetReset { bool on; ~BudgetReset() { if (on) rovit_set_cu_budget(256); } } budget_reset{ss != nullptr};
+#define EACH_HALF for (int hh = 0; hh < nh; ++hh)
   for (int i = 0; i < depth; ++i) {
     const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
     const char* q = pb + P.blk0 + (size_t)i * P.blk_stride;
     char* s = ws + L.blk0 + (size_t)i * L.blk_stride;
-    // LayerNorm1 of block 0 is a kernel of its own; every other LayerNorm of the loop is fused into the epilogue
-    // of the GEMM that produces its input (proj -> norm2, fc2 -> next block's norm1).
-    if (i == 0) RUN(rovit_layernorm_fwd(X, s + L.xhat1, (float*)(s + L.rstd1), M, D, eps, stream));
-    RUN(rovit_gemm_nt(s + L.xhat1, D, q + P.wqkv, D, M, 3 * D, D, (const float*)(q + P.bqkv), EPI_BF16, s + L.qkv, 3 * D, nullptr,
-                      nullptr, 0, nullptr, 0, nullptr, 0, stream));
-    RUN(rovit_attention_fwd(s + L.qkv, s + L.o, (float*)(s + L.lse), batch, T, H, D / H, 0.125f, stream));
     // Only token 0 of the LAST block's output is consumed (final norm + heads), and everything after the
     // attention is row-wise: run proj / LN2 / MLP of that block on the B CLS rows only (row step T).
     const bool cls_only = (i == depth - 1);
-    const int Mr = cls_only ? batch : M, rs = cls_only ? T : 1;
+    const int rs = cls_only ? T : 1;
+    // per-half views: r = first row of the half; activations are row-major with the images contiguous
+#define ROWS(ptr, width, esz) ((ptr) + (size_t)h.b0 * T * (width) * (esz))
+    // LayerNorm1 of block 0 is a kernel of its own; every other LayerNorm of the loop is fused into the epilogue
+    // of the GEMM that produces its input (proj -> norm2, fc2 -> next block's norm1).
+    if (i == 0) EACH_HALF {
+      const Half& h = halves[hh];
+      RUN(rovit_layernorm_fwd(X + (size_t)h.b0 * T * D, ROWS(s + L.xhat1, D, 2), (float*)ROWS(s + L.rstd1, 1, 4), h.nb * T, D, eps, h.st));
+    }
+    EACH_HALF {
+      const Half& h = halves[hh];
+      RUN(rovit_gemm_nt(ROWS(s + L.xhat1, D, 2), D, q + P.wqkv, D, h.nb * T, 3 * D, D, (const float*)(q + P.bqkv), EPI_BF16,
+                        ROWS(s + L.qkv, 3 * D, 2), 3 * D, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, h.st));
+    }
+    EACH_HALF {
+      const Half& h = halves[hh];
+      RUN(rovit_attention_fwd(ROWS(s + L.qkv, 3 * D, 2), ROWS(s + L.o, D, 2), (float*)(s + L.lse) + (size_t)h.b0 * H * T, h.nb, T, H, D / H,
+                              0.125f, h.st));
+    }
     // explainability tap: the attention module's output (proj(attention) + bias, before the residual add) for
     // every token of block i -- what a forward hook on `blocks[i].attn` sees (reference models/backbone.py:37-62)
     if (attn_taps && attn_taps[i])
       RUN(rovit_gemm_nt(s + L.o, D, q + P.wproj, D, M, D, D, bp[B_PROJB], EPI_BF16, attn_taps[i], D, nullptr, nullptr, 0, nullptr, 0,
                         nullptr, 0, stream));
-    if (cls_only) {
-      RUN(rovit_gemm_nt(s + L.o, D * rs, q + P.wproj, D, Mr, D, D, bp[B_PROJB], EPI_RESID, nullptr, 0, nullptr, X, D * rs, nullptr, 0,
-                        nullptr, 0, stream));
-      RUN(rovit_layernorm_fwd_rows(X, s + L.xhat2, (float*)(s + L.rstd2), batch, T, eps, stream));
-    } else {
-      RUN(rovit_gemm_resid_ln(s + L.o, D, q + P.wproj, D, M, D, bp[B_PROJB], X, s + L.xhat2, (float*)(s + L.rstd2), eps, stream));
+    EACH_HALF {
+      const Half& h = halves[hh];
+      float* Xh = X + (size_t)h.b0 * T * D;
+      if (cls_only) {
+        RUN(rovit_gemm_nt(ROWS(s + L.o, D, 2), D * rs, q + P.wproj, D, h.nb, D, D, bp[B_PROJB], EPI_RESID, nullptr, 0, nullptr, Xh, D * rs,
+                          nullptr, 0, nullptr, 0, h.st));
+        RUN(rovit_layernorm_fwd_rows(Xh, ROWS(s + L.xhat2, D, 2), (float*)ROWS(s + L.rstd2, 1, 4), h.nb, T, eps, h.st));
+      } else {
+        RUN(rovit_gemm_resid_ln(ROWS(s + L.o, D, 2), D, q + P.wproj, D, h.nb * T, D, bp[B_PROJB], Xh, ROWS(s + L.xhat2, D, 2),
+                                (float*)ROWS(s + L.rstd2, 1, 4), eps, h.st));
+      }
     }
-    RUN(rovit_gemm_nt(s + L.xhat2, D * rs, q + P.wfc1, D, Mr, MLP, D, (const float*)(q + P.bfc1), EPI_GELU, s + L.act, MLP * rs,
-                      training ? s + L.dact : nullptr, nullptr, 0, nullptr, 0, nullptr, 0, stream));
-    if (cls_only) {
-      RUN(rovit_gemm_nt(s + L.act, MLP * rs, q + P.wfc2, MLP, Mr, D, MLP, bp[B_FC2B], EPI_RESID, nullptr, 0, nullptr, X, D * rs, nullptr, 0,
-                        nullptr, 0, stream));
-    } else {
-      char* sn = ws + L.blk0 + (size_t)(i + 1) * L.blk_stride;          // next block's saved-activation area
-      RUN(rovit_gemm_resid_ln(s + L.act, MLP, q + P.wfc2, MLP, M, MLP, bp[B_FC2B], X, sn + L.xhat1, (float*)(sn + L.rstd1), eps, stream));
+    EACH_HALF {
+      const Half& h = halves[hh];
+      RUN(rovit_gemm_nt(ROWS(s + L.xhat2, D, 2), D * rs, q + P.wfc1, D, cls_only ? h.nb : h.nb * T, MLP, D, (const float*)(q + P.bfc1),
+                        EPI_GELU, ROWS(s + L.act, MLP, 2), MLP * rs, training ? ROWS(s + L.dact, MLP, 2) : nullptr, nullptr, 0, nullptr, 0,
+                        nullptr, 0, h.st));
     }
+    EACH_HALF {
+      const Half& h = halves[hh];
+      float* Xh = X + (size_t)h.b0 * T * D;
+      if (cls_only) {
+        RUN(rovit_gemm_nt(ROWS(s + L.act, MLP, 2), MLP * rs, q + P.wfc2, MLP, h.nb, D, MLP, bp[B_FC2B], EPI_RESID, nullptr, 0, nullptr, Xh,
+                          D * rs, nullptr, 0, nullptr, 0, h.st));
+      } else {
+        char* sn = ws + L.blk0 + (size_t)(i + 1) * L.blk_stride;          // next block's saved-activation area
+        RUN(rovit_gemm_resid_ln(ROWS(s + L.act, MLP, 2), MLP, q + P.wfc2, MLP, h.nb * T, MLP, bp[B_FC2B], Xh, ROWS(sn + L.xhat1, D, 2),
+                                (float*)ROWS(sn + L.rstd1, 1, 4), eps, h.st));
+      }
+    }
+#undef ROWS
   }
+#undef EACH_HALF
+  if (ss && !hand_over(ss, ss->stream, (hipStream_t)stream)) { rovit_set_error("vit_forward: event hand-over failed"); return ROVIT_ERR_LAUNCH; }
   RUN(rovit_cls_norm_fwd(X, params[P_NORM_W], params[P_NORM_B], features, (float*)(ws + L.xhat_cls), (float*)(ws + L.rstd_cls), batch,
                          T, eps, stream));
   return ROVIT_OK;
@@ -314,7 +362,7 @@ extern "C" int rovit_vit_backward(const float* d_features, const float* const* p
     char* s = ws + L.blk0 + (size_t)i * L.blk_stride;
     RUN(rovit_wgrad(ws + L.dqkv[i & 1], 3 * D, s + L.xhat1, D, M, 3 * D, D, L.s_qkv, 0, (float*)(ws + L.slab_qkv), sB));
     RUN(reduce_block(i, false, sB));
-    if (ss && !(ev_bdone[i] = hand_over(ss, sB, nullptr))) EVFAIL("event record");
+    if (ss && !(ev_bdone[i] = hand_over(ss, sB, nullptr, true))) EVFAIL("event record");
     return ROVIT_OK;
   };
   for (int i = first_block; i >= last_block; --i) {

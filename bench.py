@@ -38,10 +38,51 @@ def build_optimizer(model, lr=1e-4, wd=1e-4):
     return torch.optim.AdamW([{'params': bb, 'lr': lr / 10}, {'params': hd, 'lr': lr}], weight_decay=wd)
 
 
+def _event_avg_ms(dev, run, iters):
+    for _ in range(5):
+        run()
+    st = torch.cuda.current_stream(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        run()
+    e1.record(st)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def wgrad_roofline(dev, iters=30):
+    """Dominant kernel of the step: wgrad_kernel<false> (48 launches, ~18 % of the kernel time; rocprofv3 summary in
+    profiles/).  Timed here at its largest shape, the fc1 weight gradient G(768,192) = dPre(M,768)^T xhat(M,192) with
+    M = 50432 (the fc2 shape moves the same bytes), from device events on the stream it is launched on.  It is
+    HBM-bound (32 FLOP per byte read): achieved = algorithmic bytes / duration against the HBM peak."""
+    from rovit_hip import native
+    lib = native.load()
+    M, N, K = 256 * 197, 768, 192
+    dY = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    X = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    splits = lib.rovit_wgrad_splits(M, N, K)
+    slab = torch.empty(lib.rovit_wgrad_workspace_bytes(N, K, splits), dtype=torch.uint8, device=dev)
+
+    def run():
+        native.call('rovit_wgrad', native.ptr(dY), N, native.ptr(X), K, M, N, K, splits, 0, native.ptr(slab), native.stream_ptr())
+    ms = _event_avg_ms(dev, run, iters)
+    flops = 2.0 * M * N * K
+    # algorithmic bytes per launch (DESIGN.md section 4): read dPre (M*N) and xhat (M*K) in bf16, write G (N*K) in fp32
+    alg_bytes = 2.0 * (M * N + M * K) + 4.0 * N * K
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    return {'bound': 'hbm', 'kernel': f'wgrad_kernel<false>: fc1 weight gradient, M=50432 N=768 K=192, {splits} M-splits (32 FLOP/B, below the ridge)',
+            'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+            'avg_us': round(ms * 1e3, 2), 'algorithmic_bytes': alg_bytes,
+            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 2x read correction: profiles/r01_pmc_traffic.txt
+            # (includes the fp32 partial-sum slabs the split-M reduction writes: 18.9 MB)
+            'traffic': 127.33e6,
+            'mfma_tflops': round(flops / (ms * 1e-3) / 1e12, 1)}
+
+
 def gemm_roofline(dev, iters=30):
-    """Average duration of the dominant GEMM (fc1 forward: M=50432, N=768, K=192, GELU epilogue; the largest single
-    kernel of the step) from device events on the stream it is launched on.  Like every GEMM of this model it is
-    HBM-bound (K <= 768), so the roofline is bytes: achieved = algorithmic bytes / duration vs the HBM peak."""
+    """Second kernel of the step by time (fc1 forward: M=50432, N=768, K=192, GELU + GELU' epilogue; the largest
+    single launch), same method.  Like every GEMM of this model it is HBM-bound (K <= 768)."""
     from rovit_hip import native
     M, N, K = 256 * 197, 768, 192
     A = torch.randn(M, K, device=dev).to(torch.bfloat16)
@@ -53,24 +94,14 @@ def gemm_roofline(dev, iters=30):
     def run():
         native.call('rovit_gemm_nt', native.ptr(A), K, native.ptr(W), K, M, N, K, native.ptr(bias), 1, native.ptr(out), N,
                     native.ptr(out2), None, 0, None, 0, None, 0, native.stream_ptr())
-    for _ in range(5):
-        run()
-    st = torch.cuda.current_stream(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    for _ in range(iters):
-        run()
-    e1.record(st)
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    ms = _event_avg_ms(dev, run, iters)
     flops = 2.0 * M * N * K
     # algorithmic bytes per launch: read xhat (M*K) + W (N*K), write act + dact (2*M*N), all bf16
     alg_bytes = 2.0 * (M * K + N * K + 2 * M * N)
     gbs = alg_bytes / (ms * 1e-3) / 1e9
-    return {'bound': 'hbm', 'kernel': 'gemm_ws_kernel<6,1,64,GELU>: fc1 forward, M=50432 N=768 K=192 (85 FLOP/B, below the ridge)',
+    return {'bound': 'hbm', 'kernel': 'gemm_ws_dma_kernel<GELU>: fc1 forward, M=50432 N=768 K=192 (85 FLOP/B, below the ridge)',
             'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
             'avg_us': round(ms * 1e3, 2), 'algorithmic_bytes': alg_bytes,
-            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 2x read correction: profiles/r01_pmc_traffic.txt
             'traffic': 176.94e6,
             'mfma_tflops': round(flops / (ms * 1e-3) / 1e12, 1), 'mfma_frac_of_dense_bf16_peak': round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
 
@@ -182,7 +213,8 @@ def main():
                        'backbone_mfma_frac_of_step': round(ips / world * TRAIN_FLOP_PER_IMG / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
             'final_loss': round(final_loss, 5),
         }
-        res['roofline'] = gemm_roofline(dev)
+        res['roofline'] = wgrad_roofline(dev)
+        res['roofline_gemm'] = gemm_roofline(dev)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res), flush=True)

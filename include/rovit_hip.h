@@ -165,6 +165,8 @@ int rovit_mix_images(const float* images, float* out, const long long* perm, int
  * or NULL; t = 1-based step count for the bias correction.
  * ------------------------------------------------------------------------------------------------------------ */
 int rovit_sq_norm_accum(const float* g, size_t n, float* out_sq, rovit_stream_t stream);
+/* clip_grad_norm_ coefficient on the device: *norm_out = sqrt(*sq) (optional), *coef = min(1, max_norm / (norm + 1e-6)) */
+int rovit_clip_coef(const float* sq, float max_norm, float* coef, float* norm_out, rovit_stream_t stream);
 int rovit_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, const float* grad_scale, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int t, rovit_stream_t stream);
 

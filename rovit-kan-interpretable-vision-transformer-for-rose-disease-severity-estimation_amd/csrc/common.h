@@ -98,6 +98,14 @@ __device__ __forceinline__ float wave_sum16(float v) {   // sum over the 16 lane
   v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
   return v;
 }
+// same sum with DPP row rotations (no LDS-pipeline instruction): every lane of a 16-lane row gets the row total
+__device__ __forceinline__ float row_sum16_dpp(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+}
 __device__ __forceinline__ float wave_sum64(float v) {
   v = wave_sum16(v); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
   return v;

@@ -369,15 +369,21 @@ __global__ __launch_bounds__(256 * WK, 2) void gemm_ws_kernel(const GemmArgs g, 
             }
             float4* xp = (float4*)(g.xres + (size_t)m * g.ldx);
             if (EPI == EPI_RESID_LN) {
-              // X += bf16(branch output); then (optionally) the next LayerNorm: xhat (bf16) and rstd
+              // X += bf16(branch output); then (optionally) the next LayerNorm: xhat (bf16) and rstd.
+              // All arithmetic first, all stores last.  (With the X stores in the middle, one build of this pass
+              // -- three back-to-back 16-byte stores followed at once by packed adds that recycled the stores'
+              // address registers -- produced a wrong row sum in lanes 48-63 of a wave in ~15 % of launches at
+              // M = 50432, on two different MI355X; see DESIGN.md "observed hazard".  tools/stress_ln.py and
+              // tests/test_gpu_stress.py screen for it.)
+              float4 xs[3];
               float sum = 0.f;
 #pragma unroll
               for (int i = 0; i < 3; ++i) {
                 float4 x = xp[16 * i + c];
                 x.x += v[4 * i]; x.y += v[4 * i + 1]; x.z += v[4 * i + 2]; x.w += v[4 * i + 3];
-                xp[16 * i + c] = x;
+                xs[i] = x;
                 v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
-                sum += x.x + x.y + x.z + x.w;
+                sum += (x.x + x.y) + (x.z + x.w);
               }
               if (g.out) {
                 const float mean = wave_sum16(sum) * (1.f / 192.f);
@@ -385,13 +391,21 @@ __global__ __launch_bounds__(256 * WK, 2) void gemm_ws_kernel(const GemmArgs g, 
 #pragma unroll
                 for (int e = 0; e < 12; ++e) { v[e] -= mean; qs += v[e] * v[e]; }
                 const float r = rsqrtf(wave_sum16(qs) * (1.f / 192.f) + g.eps);
-                bf16x4* hp = (bf16x4*)(g.out + (size_t)m * g.ldo);
+                bf16x4 hq[3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                   f32x4 t = {v[4 * i] * r, v[4 * i + 1] * r, v[4 * i + 2] * r, v[4 * i + 3] * r};
-                  hp[16 * i + c] = pack4(t);
+                  hq[i] = pack4(t);
                 }
+                bf16x4* hp = (bf16x4*)(g.out + (size_t)m * g.ldo);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) xp[16 * i + c] = xs[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) hp[16 * i + c] = hq[i];
                 if (c == 0) g.rstd_out[m] = r;
+              } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) xp[16 * i + c] = xs[i];
               }
             } else {
               // LayerNorm backward behind a dgrad: v = dxhat row (affine already folded into the weight),

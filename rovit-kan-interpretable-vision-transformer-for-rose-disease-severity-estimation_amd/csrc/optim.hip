@@ -57,7 +57,22 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
   }
 }
 
+// clip_grad_norm_ coefficient from the accumulated squared norm: norm = sqrt(sq), coef = min(1, max_norm / (norm + 1e-6))
+__global__ void clip_coef_kernel(const float* __restrict__ sq, float max_norm, float* __restrict__ coef, float* __restrict__ norm_out) {
+  const float n = sqrtf(*sq);
+  if (norm_out) *norm_out = n;
+  *coef = fminf(1.f, max_norm / (n + 1e-6f));
+}
+
 }  // namespace
+
+extern "C" int rovit_clip_coef(const float* sq, float max_norm, float* coef, float* norm_out, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(sq && coef, ROVIT_ERR_NULL, "clip_coef: null pointer");
+  ROVIT_CHECK_ARG(max_norm > 0.f, ROVIT_ERR_SHAPE, "clip_coef: max_norm must be positive");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sq, max_norm, coef, norm_out);
+  ROVIT_CHECK_LAUNCH("clip_coef_kernel");
+  return ROVIT_OK;
+}
 
 // out_sq (device scalar) += sum g^2 ; the caller zeroes it (so several buffers can accumulate into one norm)
 extern "C" int rovit_sq_norm_accum(const float* g, size_t n, float* out_sq, rovit_stream_t stream) {

@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, 'lib', 'librovit_hip.so')
+LIB_PATH = os.environ.get('ROVIT_HIP_LIB') or os.path.join(_PKG_ROOT, 'lib', 'librovit_hip.so')   # env override: developer A/B builds
 
 _lib: Optional[C.CDLL] = None
 
@@ -59,6 +59,7 @@ SIGNATURES = {
     'rovit_scale_buffers': (_i, [_vp, _vp, _i, _vp, _vp]),
     'rovit_sq_norm_accum': (_i, [_vp, _sz, _vp, _vp]),
     'rovit_mix_images': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp]),
+    'rovit_clip_coef': (_i, [_vp, _f, _vp, _vp, _vp]),
     'rovit_adamw_flat': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _i, _vp]),
 }
 

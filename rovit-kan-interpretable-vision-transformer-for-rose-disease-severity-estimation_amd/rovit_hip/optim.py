@@ -3,18 +3,32 @@
 Reference: training/optimizer.py:7-32 (AdamW; parameters whose name contains 'backbone' at lr/10, the rest at lr;
 weight_decay 1e-4) and training/trainer.py:123-128,137-141 (clip_grad_norm_(parameters, 1.0) before the step).
 
-The backbone's 5.5 M parameters are re-homed into ONE flat fp32 buffer (each nn.Parameter keeps its identity and
-becomes a view), next to the flat gradient buffer the HIP backward already writes, so their whole update is two
-launches (rovit_sq_norm_accum + rovit_adamw_flat).  The ~0.18 M head/KAN parameters keep torch.optim.AdamW.
+Every parameter is re-homed into a flat fp32 buffer (each nn.Parameter keeps its identity and becomes a view):
+* the backbone's 5.5 M parameters next to the flat gradient buffer the HIP backward already writes;
+* the ~0.18 M head / KAN parameters in a second buffer, one 16-byte-aligned segment per top-level module, whose
+  gradients (separate autograd tensors) are packed by one cat kernel per step.
+The whole step is then: squared norms (rovit_sq_norm_accum per buffer) -> clip coefficient on the device
+(rovit_clip_coef) -> fused clip-scale + decoupled weight decay + Adam (rovit_adamw_flat per buffer / active segment).
+A module whose parameters received no gradient this step (curriculum stage gating) is skipped entirely, like
+torch.optim.AdamW skips parameters with ``grad is None``; its bias-correction step count does not advance.
 """
 from __future__ import annotations
 
-from typing import Optional
+from typing import List, Optional
 
 import torch
 
 from . import native
 from .native import call, ptr, stream_ptr
+
+
+class _Segment:
+    """Parameters of one top-level module, contiguous in the flat buffer."""
+
+    def __init__(self, name: str, params: List[torch.nn.Parameter], offset: int):
+        self.name, self.params, self.offset = name, params, offset
+        self.numel = sum(p.numel() for p in params)
+        self.t = 0
 
 
 class RoViTAdamW:
@@ -29,22 +43,44 @@ class RoViTAdamW:
         dev = self.bb_params[0].device
         if dev.type != 'cuda':
             raise native.RovitHipError('RoViTAdamW needs the model on a CUDA/HIP device (call model.to(device) first)')
-        total = sum(p.numel() for p in self.bb_params)
-        self.p_flat = torch.empty(total, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.bb_params:                        # re-home every backbone parameter into the flat buffer
-            n = p.numel()
-            view = self.p_flat[off:off + n].view_as(p)
-            view.copy_(p.data)
-            p.data = view
-            off += n
+        self.p_flat = self._rehome(self.bb_params, [0], sum(p.numel() for p in self.bb_params), dev)
         self.m_flat = torch.zeros_like(self.p_flat)
         self.v_flat = torch.zeros_like(self.p_flat)
         self.t = 0
-        self.other_params = [p for n, p in model.named_parameters() if not n.startswith('backbone.')]
-        self.other = torch.optim.AdamW(self.other_params, lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
+        # head / KAN parameters: one segment per top-level module, segment starts padded to 4 floats (16 bytes)
+        groups = {}
+        for n, p in model.named_parameters():
+            if not n.startswith('backbone.'):
+                groups.setdefault(n.split('.')[0], []).append(p)
+        self.segments: List[_Segment] = []
+        off = 0
+        for name, ps in groups.items():
+            self.segments.append(_Segment(name, ps, off))
+            off += (self.segments[-1].numel + 3) // 4 * 4
+        self.other_params = [p for s in self.segments for p in s.params]
+        self.o_flat = torch.zeros(max(off, 4), dtype=torch.float32, device=dev)
+        for s in self.segments:
+            self._rehome(s.params, [s.offset], s.numel, dev, self.o_flat)
+        self.o_grad = torch.zeros_like(self.o_flat)
+        self.o_m = torch.zeros_like(self.o_flat)
+        self.o_v = torch.zeros_like(self.o_flat)
         self._sq = torch.zeros((), dtype=torch.float32, device=dev)
+        self._coef = torch.ones((), dtype=torch.float32, device=dev)
+        self._norm = torch.zeros((), dtype=torch.float32, device=dev)
         self.last_grad_norm: Optional[torch.Tensor] = None
+
+    @staticmethod
+    def _rehome(params, offsets, total, dev, flat=None):
+        if flat is None:
+            flat = torch.empty(total, dtype=torch.float32, device=dev)
+        off = offsets[0]
+        for p in params:
+            n = p.numel()
+            view = flat[off:off + n].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            off += n
+        return flat
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.bb_params + self.other_params:
@@ -56,31 +92,53 @@ class RoViTAdamW:
     def _backbone_active(self) -> bool:
         return self.bb_params[0].requires_grad and self.bb_params[0].grad is not None
 
+    def _pack_grads(self) -> List[_Segment]:
+        """Copy the active segments' gradients into o_grad (one cat kernel per run of fully populated segments)."""
+        active = []
+        for s in self.segments:
+            grads = [p.grad for p in s.params]
+            if all(g is None for g in grads):
+                continue
+            pieces = [(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(grads, s.params)]
+            torch.cat(pieces, out=self.o_grad[s.offset:s.offset + s.numel])
+            active.append(s)
+        return active
+
     @torch.no_grad()
     def step(self):
         eng = self.engine
+        sp = stream_ptr()
         bb = self._backbone_active()
         if bb and (eng.grad_views is None or self.bb_params[0].grad.data_ptr() != eng.grad_views[0].data_ptr()):
             raise native.RovitHipError('backbone gradients are not the engine-owned flat buffer')
-        others = [p for p in self.other_params if p.grad is not None]
-        scale = None
+        active = self._pack_grads()
+        coef = None
         if self.max_grad_norm is not None:
             self._sq.zero_()
             if bb:
-                call('rovit_sq_norm_accum', ptr(eng.grad_flat), eng.grad_flat.numel(), ptr(self._sq), stream_ptr())
-            if others:
-                norms = torch._foreach_norm([p.grad for p in others])
-                self._sq.add_(torch.stack(norms).square_().sum())
-            total_norm = self._sq.sqrt()
-            self.last_grad_norm = total_norm
-            scale = (self.max_grad_norm / (total_norm + 1e-6)).clamp_(max=1.0)    # clip_grad_norm_ semantics
-            if others:
-                torch._foreach_mul_([p.grad for p in others], scale)
-        self.t += 1
+                call('rovit_sq_norm_accum', ptr(eng.grad_flat), eng.grad_flat.numel(), ptr(self._sq), sp)
+            for s in active:            # padding floats of o_grad stay zero, so whole aligned segments can be summed
+                call('rovit_sq_norm_accum', ptr(self.o_grad[s.offset:]), (s.numel + 3) // 4 * 4, ptr(self._sq), sp)
+            call('rovit_clip_coef', ptr(self._sq), float(self.max_grad_norm), ptr(self._coef), ptr(self._norm), sp)
+            self.last_grad_norm = self._norm
+            coef = ptr(self._coef)
         if bb:
+            self.t += 1
             call('rovit_adamw_flat', ptr(self.p_flat), ptr(eng.grad_flat), ptr(self.m_flat), ptr(self.v_flat),
-                 self.p_flat.numel(), ptr(scale) if scale is not None else None, self.lr / 10.0, self.betas[0], self.betas[1],
-                 self.eps, self.wd, self.t, stream_ptr())
+                 self.p_flat.numel(), coef, self.lr / 10.0, self.betas[0], self.betas[1], self.eps, self.wd, self.t, sp)
             eng._prep_key = None            # parameters changed behind torch's version counters: re-prepare weights
-        if others:
-            self.other.step()
+        # consecutive active segments with the same step count share one launch (the usual case: all of them)
+        i = 0
+        while i < len(active):
+            j = i
+            while (j + 1 < len(active) and active[j + 1].t == active[i].t and
+                   active[j + 1].offset == active[j].offset + (active[j].numel + 3) // 4 * 4):
+                j += 1
+            first, last = active[i], active[j]
+            n = last.offset + last.numel - first.offset
+            for s in active[i:j + 1]:
+                s.t += 1
+            o = first.offset
+            call('rovit_adamw_flat', ptr(self.o_flat[o:]), ptr(self.o_grad[o:]), ptr(self.o_m[o:]), ptr(self.o_v[o:]), n, coef,
+                 self.lr, self.betas[0], self.betas[1], self.eps, self.wd, first.t, sp)
+            i = j + 1

@@ -140,7 +140,13 @@ def main():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--buckets', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--roofline-only', action='store_true',
+                    help='run only the two roofline kernel measurements (the command profiles/r01_roofline_kernel_stats.csv is taken from)')
     args = ap.parse_args()
+    if args.roofline_only:
+        dev = torch.device('cuda:0')
+        print(json.dumps({'roofline': wgrad_roofline(dev), 'roofline_gemm': gemm_roofline(dev)}), flush=True)
+        return
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

@@ -11,6 +11,7 @@
 // MFMA "A" operand) so that each lane ends up with 4 consecutive output columns of one row: 8-byte bf16 /
 // 16-byte fp32 epilogue accesses.  Workgroup ids are remapped so that all column tiles of one row panel (and
 // all output tiles of one M-split in wgrad) run on the same XCD and share that XCD's L2.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -1017,7 +1018,8 @@ extern "C" size_t rovit_wgrad_workspace_bytes(int N, int K, int splits) {
 
 extern "C" int rovit_wgrad_splits(int M, int N, int K) {
   const int tiles = (N / WG_T) * (K / WG_T);
-  int s = (512 + tiles - 1) / tiles;               // ~2 workgroups per CU: measured best trade against slab traffic
+  static const int target = getenv("ROVIT_WGRAD_WGS") ? atoi(getenv("ROVIT_WGRAD_WGS")) : 512;
+  int s = (target + tiles - 1) / tiles;            // ~2 workgroups per CU: measured best trade against slab traffic
   s = (s + 7) / 8 * 8;
   const int max_s = (M + WG_MSTEP - 1) / WG_MSTEP;
   if (s > max_s) s = max_s;

@@ -103,6 +103,12 @@ int rovit_vit_forward_taps(const float* images, const float* const* params, cons
                            void* const* attn_taps, int batch, int depth, rovit_stream_t stream);
 int rovit_vit_backward(const float* d_features, const float* const* params, const void* prep, void* workspace,
                        float* const* grads, int batch, int depth, int first_block, int last_block, rovit_stream_t stream);
+/* rovit_vit_backward for a data-parallel caller: for last_block > 0 the call does not wait for the range's weight
+ * gradients on `stream`; `notify_stream` (the caller's reduction stream) is made to wait for them instead.  Issue the
+ * ranges in order down to last_block == 0; that call joins everything into `stream`. */
+int rovit_vit_backward_notify(const float* d_features, const float* const* params, const void* prep, void* workspace,
+                              float* const* grads, int batch, int depth, int first_block, int last_block,
+                              rovit_stream_t stream, rovit_stream_t notify_stream);
 
 /* ---- the individual backbone kernels (used by rovit_vit_* and exposed for unit tests / profiling) ---------- */
 /* C = A(M,K) W(N,K)^T + bias with a fused epilogue:

@@ -120,6 +120,9 @@ struct SideStream {
   hipStream_t stream = nullptr;
   std::vector<hipEvent_t> events;
   size_t next = 0;
+  // backward state carried from one block range to the next when the join was deferred (rovit_vit_backward_notify)
+  hipEvent_t ev_bdone[64] = {};
+  bool carry = false;
   hipEvent_t get() {
     if (next == events.size()) {
       hipEvent_t e;
@@ -321,9 +324,10 @@ extern "C" int rovit_vit_forward_taps(const float* images, const float* const* p
 // runs the final-norm backward from d_features; last_block == 0 also produces the patch-embed / pos / cls
 // gradients.  Splitting the range lets the caller start a gradient all-reduce between calls.
 // grads[] mirrors params[]; every entry of the processed range is overwritten.
-extern "C" int rovit_vit_backward(const float* d_features, const float* const* params, const void* prep, void* workspace,
-                                  float* const* grads, int batch, int depth, int first_block, int last_block,
-                                  rovit_stream_t stream) {
+namespace {
+int vit_backward_impl(const float* d_features, const float* const* params, const void* prep, void* workspace,
+                      float* const* grads, int batch, int depth, int first_block, int last_block, rovit_stream_t stream,
+                      bool defer_join, hipStream_t notify) {
   RUN(check_common(params, prep, workspace, batch, depth));
   ROVIT_CHECK_ARG(grads, ROVIT_ERR_NULL, "vit_backward: null grads");
   ROVIT_CHECK_ARG(first_block < depth && last_block >= 0 && first_block >= last_block, ROVIT_ERR_SHAPE,
@@ -354,8 +358,13 @@ extern "C" int rovit_vit_backward(const float* d_features, const float* const* p
   hipStream_t sA = (hipStream_t)stream;
   SideStream* ss = two_streams_enabled() ? side_stream() : nullptr;
   hipStream_t sB = ss ? ss->stream : sA;
-  if (ss) ss->next = 0;
-  hipEvent_t ev_bdone[64] = {};
+  static hipEvent_t no_events[64];
+  if (ss && !(ss->carry && first_block != depth - 1)) {      // a new backward pass, or the previous range was joined
+    ss->next = 0;
+    for (auto& e : ss->ev_bdone) e = nullptr;
+  }
+  if (ss) ss->carry = false;
+  hipEvent_t* ev_bdone = ss ? ss->ev_bdone : no_events;
   int pending = -1;                                   // block whose B4/B5 have not been issued yet
 #define EVFAIL(what) do { rovit_set_error("vit_backward: " what " failed"); return ROVIT_ERR_LAUNCH; } while (0)
   auto reduce_block = [&](int i, bool cls_only, rovit_stream_t st) -> int {
@@ -432,7 +441,13 @@ extern "C" int rovit_vit_backward(const float* d_features, const float* const* p
   if (pending >= 0) {
     if (ss && !hand_over(ss, sA, sB)) EVFAIL("event hand-over");
     RUN(issue_b45(pending));
-    if (ss && !hand_over(ss, sB, sA)) EVFAIL("event hand-over");       // join: the gradients of the range are final on A
+    if (ss && defer_join && last_block > 0) {
+      // the gradients of this range are final once B drains: tell the caller's reduction stream, do not stall A
+      if (!hand_over(ss, sB, notify)) EVFAIL("event hand-over");
+      ss->carry = true;
+    } else if (ss && !hand_over(ss, sB, sA)) {       // join: the gradients of the range are final on A
+      EVFAIL("event hand-over");
+    }
   }
 #undef EVFAIL
   if (last_block == 0) {
@@ -443,3 +458,22 @@ extern "C" int rovit_vit_backward(const float* d_features, const float* const* p
   }
   return ROVIT_OK;
 }
+}  // namespace
+
+extern "C" int rovit_vit_backward(const float* d_features, const float* const* params, const void* prep, void* workspace,
+                                  float* const* grads, int batch, int depth, int first_block, int last_block,
+                                  rovit_stream_t stream) {
+  return vit_backward_impl(d_features, params, prep, workspace, grads, batch, depth, first_block, last_block, stream, false, nullptr);
+}
+
+// Same, for a data-parallel caller that reduces each block range while the next one runs: for last_block > 0 the
+// weight-gradient stream is NOT joined back into `stream`; instead `notify_stream` (the caller's reduction stream) is
+// made to wait until the gradients of this range are final.  Ranges must then be issued in order down to
+// last_block == 0, whose call joins everything into `stream`.
+extern "C" int rovit_vit_backward_notify(const float* d_features, const float* const* params, const void* prep, void* workspace,
+                                         float* const* grads, int batch, int depth, int first_block, int last_block,
+                                         rovit_stream_t stream, rovit_stream_t notify_stream) {
+  return vit_backward_impl(d_features, params, prep, workspace, grads, batch, depth, first_block, last_block, stream, true,
+                           (hipStream_t)notify_stream);
+}
+

@@ -188,9 +188,11 @@ class VitEngine:
         self.grad_stage: Optional[torch.Tensor] = None
         self.grad_views: Optional[List[torch.Tensor]] = None
         self.stage_views: Optional[List[torch.Tensor]] = None
-        # called as hook(engine, first_block, last_block) after each backward range has been enqueued
+        # called as hook(engine, first_block, last_block, ordered) after each backward range has been enqueued
+        # (`ordered` = the reduction stream already waits for the range's gradients, see rovit_vit_backward_notify)
         self.backward_ranges: Optional[Sequence] = None
         self.range_hook = None
+        self.notify_stream: Optional[torch.cuda.Stream] = None
 
     # -- prepared weights ---------------------------------------------------------------------
     def prepare(self, params: Sequence[torch.Tensor]):
@@ -278,11 +280,18 @@ class VitFn(torch.autograd.Function):
         parr, garr = ptr_array(params), ptr_array(targets)
         depth = engine.depth
         ranges = engine.backward_ranges or [(depth - 1, 0)]
+        hooked = engine.range_hook is not None and fresh
         for first, last in ranges:
-            call('rovit_vit_backward', ptr(dfeat), parr, ptr(engine.prep), ptr(ctx.ws), garr, ctx.batch, depth,
-                 first, last, stream_ptr())
-            if engine.range_hook is not None and fresh:
-                engine.range_hook(engine, first, last)
+            if hooked and engine.notify_stream is not None and last > 0:
+                # the range's gradients become visible on the reduction stream; this stream is not stalled
+                call('rovit_vit_backward_notify', ptr(dfeat), parr, ptr(engine.prep), ptr(ctx.ws), garr, ctx.batch, depth,
+                     first, last, stream_ptr(), engine.notify_stream.cuda_stream)
+                engine.range_hook(engine, first, last, True)
+            else:
+                call('rovit_vit_backward', ptr(dfeat), parr, ptr(engine.prep), ptr(ctx.ws), garr, ctx.batch, depth,
+                     first, last, stream_ptr())
+                if hooked:
+                    engine.range_hook(engine, first, last, False)
         if fresh:
             for p, v in zip(params, engine.grad_views):
                 if p.requires_grad:
@@ -290,7 +299,7 @@ class VitFn(torch.autograd.Function):
         elif owned:
             engine.grad_flat.add_(engine.grad_stage)
             if engine.range_hook is not None:          # accumulated gradients: one bucket over everything
-                engine.range_hook(engine, depth - 1, 0)
+                engine.range_hook(engine, depth - 1, 0, False)
         else:
             if engine.range_hook is not None:
                 raise native.RovitHipError('data-parallel sync needs engine-owned gradients: do not replace '

@@ -47,7 +47,13 @@ class FlatBucketAllReduce:
         t.div_(self.world)
         return None
 
-    def reduce_slice(self, flat: torch.Tensor, offset: int, numel: int):
+    def stream_for(self, device) -> Optional[torch.cuda.Stream]:
+        if self._stream is None and self.use_side_stream and torch.cuda.is_available():
+            self._stream = torch.cuda.Stream(device=device)
+        return self._stream
+
+    def reduce_slice(self, flat: torch.Tensor, offset: int, numel: int, ordered: bool = False):
+        """ordered=True: the side stream has already been made to wait for the slice (rovit_vit_backward_notify)."""
         self.issued.append((offset, numel))
         if (self.world == 1 and not self.force) or numel == 0:
             return
@@ -55,7 +61,8 @@ class FlatBucketAllReduce:
         if flat.is_cuda and self.use_side_stream:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=flat.device)
-            self._stream.wait_stream(torch.cuda.current_stream(flat.device))     # slice is final on the main stream
+            if not ordered:
+                self._stream.wait_stream(torch.cuda.current_stream(flat.device))     # slice is final on the main stream
             with torch.cuda.stream(self._stream):
                 w = self._avg(piece)
             if w is not None:
@@ -93,6 +100,9 @@ class GradSync:
         if self.active:
             self.engine.backward_ranges = self.ranges
             self.engine.range_hook = self._on_range
+            dev = params[0].device
+            if dev.type == 'cuda':
+                self.engine.notify_stream = self.reducer.stream_for(dev)
 
     def slice_for(self, first: int, last: int) -> Tuple[int, int]:
         off = self.prefix + last * self.block_numel
@@ -101,9 +111,9 @@ class GradSync:
             off, n = 0, n + self.prefix
         return off, n
 
-    def _on_range(self, engine, first: int, last: int):
+    def _on_range(self, engine, first: int, last: int, ordered: bool = False):
         off, n = self.slice_for(first, last)
-        self.reducer.reduce_slice(engine.grad_flat, off, n)
+        self.reducer.reduce_slice(engine.grad_flat, off, n, ordered)
 
     def finish(self):
         """Call after loss.backward(): reduce the small head/KAN gradients, then join the side stream."""

@@ -347,3 +347,49 @@ def test_two_stream_schedule_vs_oracle_and_on_a_side_stream():
             assert float((p.grad - g0[k]).abs().max()) <= 1e-5 * float(g0[k].abs().max()), k
         else:
             assert torch.equal(p.grad, g0[k]), k
+
+
+def test_bucketed_grad_sync_one_rank_matches_plain_backward():
+    """GradSync with the RCCL process group of ONE rank (collectives forced): block-range backward with the deferred
+    join (rovit_vit_backward_notify) + all-reduce on the side stream must leave exactly the gradients of the plain
+    backward (AVG over one rank is the identity)."""
+    import torch.distributed as dist
+    from models.rovit_kan import RoViTKAN
+    from rovit_hip.losses import JointLoss
+    from rovit_hip.parallel import GradSync
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    torch.manual_seed(3)
+    m = RoViTKAN(pretrained=False).to(dev()).eval()
+    x = torch.randn(20, 3, 224, 224, device=dev())
+    y = torch.randint(0, 4, (20,), device=dev())
+    lf = JointLoss()
+
+    def grads():
+        for p in m.parameters():
+            p.grad = None
+        lf(m(x), y, y, 4)['total_loss'].backward()
+        return {n: p.grad.clone() for n, p in m.named_parameters()}
+    g_plain = grads()
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        sync = GradSync(m, buckets=3, force=True)
+        assert sync.active and m.backbone.model.engine.notify_stream is not None
+        for p in m.parameters():
+            p.grad = None
+        lf(m(x), y, y, 4)['total_loss'].backward()
+        sync.finish()
+        torch.cuda.synchronize()
+        assert len(sync.reducer.issued) == 4                       # 3 backbone buckets + heads
+        for n, p in m.named_parameters():
+            if 'norm' in n:
+                assert float((p.grad - g_plain[n]).abs().max()) <= 1e-5 * float(g_plain[n].abs().max() + 1e-12), n
+            else:
+                assert torch.equal(p.grad, g_plain[n]), n
+    finally:
+        eng = m.backbone.model.engine
+        eng.backward_ranges = eng.range_hook = eng.notify_stream = None
+        if created:
+            dist.destroy_process_group()

@@ -393,3 +393,47 @@ def test_bucketed_grad_sync_one_rank_matches_plain_backward():
         eng.backward_ranges = eng.range_hook = eng.notify_stream = None
         if created:
             dist.destroy_process_group()
+
+
+def test_training_loop_reduces_loss_and_respects_stage_gating():
+    """A short real training loop on one fixed batch (RoViTAdamW + fused JointLoss + HIP forward/backward): the loss
+    goes down, parameters of heads that are inactive at the current curriculum stage are not touched (torch.optim
+    skips parameters without gradients; so does the flat optimizer, per module segment), and they start moving once
+    their stage is reached."""
+    from models.rovit_kan import RoViTKAN
+    from rovit_hip.optim import RoViTAdamW
+    from rovit_hip.losses import JointLoss
+    torch.manual_seed(11)
+    m = RoViTKAN(pretrained=False, dropout=0.0).to(dev()).train()
+    opt = RoViTAdamW(m, lr=2e-3, weight_decay=1e-4, max_grad_norm=1.0)
+    lf = JointLoss()
+    x = torch.randn(32, 3, 224, 224, device=dev())
+    y = torch.randint(0, 4, (32,), device=dev())
+
+    def snapshot():
+        return {n: p.detach().clone() for n, p in m.named_parameters()}
+
+    def run(stage, steps):
+        m.curriculum_stage = stage
+        losses = []
+        for _ in range(steps):
+            opt.zero_grad()
+            loss = lf(m(x), y, y, stage)['total_loss']
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        return losses
+    before = snapshot()
+    l1 = run(1, 12)
+    after1 = snapshot()
+    assert l1[-1] < 0.8 * l1[0], l1
+    moved = {n.split('.')[0] for n in before if not torch.equal(before[n], after1[n])}
+    assert moved == {'backbone', 'classification_head'}, moved
+    l4 = run(4, 12)
+    after4 = snapshot()
+    assert l4[-1] < 0.8 * l4[0], l4
+    moved = {n.split('.')[0] for n in before if not torch.equal(after1[n], after4[n])}
+    assert moved == {'backbone', 'classification_head', 'ordinal_head', 'uncertainty_head', 'kan_module'}, moved
+    assert all(torch.isfinite(p).all() for p in m.parameters())
+    seg_t = {s.name: s.t for s in opt.segments}
+    assert seg_t['classification_head'] == 24 and seg_t['kan_module'] == 12 and opt.t == 24, seg_t

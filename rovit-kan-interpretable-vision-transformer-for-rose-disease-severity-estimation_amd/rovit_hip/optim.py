@@ -11,6 +11,10 @@ The whole step is then: squared norms (rovit_sq_norm_accum per buffer) -> clip c
 (rovit_clip_coef) -> fused clip-scale + decoupled weight decay + Adam (rovit_adamw_flat per buffer / active segment).
 A module whose parameters received no gradient this step (curriculum stage gating) is skipped entirely, like
 torch.optim.AdamW skips parameters with ``grad is None``; its bias-correction step count does not advance.
+
+``RoViTAdamW`` is a ``torch.optim.Optimizer`` with the reference's two parameter groups (``param_groups[0]`` =
+backbone at lr/10, ``param_groups[1]`` = heads/KAN at lr), so ``CosineAnnealingLR`` (training/optimizer.py:35-44) and
+``get_lr`` (:47-49) work on it unchanged; ``build_optimizer`` / ``build_scheduler`` / ``get_lr`` mirror that file.
 """
 from __future__ import annotations
 
@@ -31,11 +35,10 @@ class _Segment:
         self.t = 0
 
 
-class RoViTAdamW:
+class RoViTAdamW(torch.optim.Optimizer):
     def __init__(self, model, lr: float = 1e-4, weight_decay: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  max_grad_norm: Optional[float] = 1.0):
         self.model = model
-        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.max_grad_norm = max_grad_norm
         self.vit = model.backbone.model
         self.engine = self.vit.engine
@@ -64,6 +67,8 @@ class RoViTAdamW:
         self.o_grad = torch.zeros_like(self.o_flat)
         self.o_m = torch.zeros_like(self.o_flat)
         self.o_v = torch.zeros_like(self.o_flat)
+        super().__init__([{'params': list(self.bb_params), 'lr': lr / 10.0}, {'params': list(self.other_params), 'lr': lr}],
+                         dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._sq = torch.zeros((), dtype=torch.float32, device=dev)
         self._coef = torch.ones((), dtype=torch.float32, device=dev)
         self._norm = torch.zeros((), dtype=torch.float32, device=dev)
@@ -82,13 +87,6 @@ class RoViTAdamW:
             off += n
         return flat
 
-    def zero_grad(self, set_to_none: bool = True):
-        for p in self.bb_params + self.other_params:
-            if set_to_none:
-                p.grad = None
-            elif p.grad is not None:
-                p.grad.zero_()
-
     def _backbone_active(self) -> bool:
         return self.bb_params[0].requires_grad and self.bb_params[0].grad is not None
 
@@ -105,8 +103,13 @@ class RoViTAdamW:
         return active
 
     @torch.no_grad()
-    def step(self):
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         eng = self.engine
+        gb, gh = self.param_groups[0], self.param_groups[1]
         sp = stream_ptr()
         bb = self._backbone_active()
         if bb and (eng.grad_views is None or self.bb_params[0].grad.data_ptr() != eng.grad_views[0].data_ptr()):
@@ -125,7 +128,7 @@ class RoViTAdamW:
         if bb:
             self.t += 1
             call('rovit_adamw_flat', ptr(self.p_flat), ptr(eng.grad_flat), ptr(self.m_flat), ptr(self.v_flat),
-                 self.p_flat.numel(), coef, self.lr / 10.0, self.betas[0], self.betas[1], self.eps, self.wd, self.t, sp)
+                 self.p_flat.numel(), coef, float(gb['lr']), gb['betas'][0], gb['betas'][1], gb['eps'], gb['weight_decay'], self.t, sp)
             eng._prep_key = None            # parameters changed behind torch's version counters: re-prepare weights
         # consecutive active segments with the same step count share one launch (the usual case: all of them)
         i = 0
@@ -140,5 +143,40 @@ class RoViTAdamW:
                 s.t += 1
             o = first.offset
             call('rovit_adamw_flat', ptr(self.o_flat[o:]), ptr(self.o_grad[o:]), ptr(self.o_m[o:]), ptr(self.o_v[o:]), n, coef,
-                 self.lr, self.betas[0], self.betas[1], self.eps, self.wd, first.t, sp)
+                 float(gh['lr']), gh['betas'][0], gh['betas'][1], gh['eps'], gh['weight_decay'], first.t, sp)
             i = j + 1
+        return loss
+
+    def state_dict(self):
+        """param_groups as torch reports them + the flat moment buffers and step counts."""
+        sd = super().state_dict()
+        sd['rovit_flat'] = {'m_flat': self.m_flat.clone(), 'v_flat': self.v_flat.clone(), 'o_m': self.o_m.clone(),
+                            'o_v': self.o_v.clone(), 't': self.t, 'segment_t': {s.name: s.t for s in self.segments}}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        flat = state_dict.get('rovit_flat')
+        super().load_state_dict({k: v for k, v in state_dict.items() if k != 'rovit_flat'})
+        if flat is not None:
+            self.m_flat.copy_(flat['m_flat']); self.v_flat.copy_(flat['v_flat'])
+            self.o_m.copy_(flat['o_m']); self.o_v.copy_(flat['o_v'])
+            self.t = int(flat['t'])
+            for s in self.segments:
+                s.t = int(flat['segment_t'].get(s.name, 0))
+
+
+def build_optimizer(model, config) -> RoViTAdamW:
+    """training/optimizer.py:7-32 on the HIP path (clip_grad_norm_ of trainer.py:123-126 is inside step())."""
+    clip = getattr(getattr(config, 'flags', None), 'gradient_clip', 1.0)
+    return RoViTAdamW(model, lr=config.train.learning_rate, weight_decay=config.train.weight_decay, max_grad_norm=clip)
+
+
+def build_scheduler(optimizer, config):
+    """training/optimizer.py:35-44."""
+    return torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=config.train.epochs, eta_min=1e-6)
+
+
+def get_lr(optimizer) -> float:
+    """training/optimizer.py:47-49: the first group's rate (the backbone's)."""
+    for group in optimizer.param_groups:
+        return group['lr']

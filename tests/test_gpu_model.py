@@ -437,3 +437,42 @@ def test_training_loop_reduces_loss_and_respects_stage_gating():
     assert all(torch.isfinite(p).all() for p in m.parameters())
     seg_t = {s.name: s.t for s in opt.segments}
     assert seg_t['classification_head'] == 24 and seg_t['kan_module'] == 12 and opt.t == 24, seg_t
+
+
+def test_optimizer_is_a_torch_optimizer_scheduler_and_state_dict_round_trip():
+    """CosineAnnealingLR / get_lr of the reference (training/optimizer.py:35-49) drive RoViTAdamW's two parameter
+    groups; state_dict round-trips the flat moments so a resumed optimizer takes the identical next step."""
+    import copy
+    from types import SimpleNamespace
+    from models.rovit_kan import RoViTKAN
+    from rovit_hip.optim import RoViTAdamW, build_optimizer, build_scheduler, get_lr
+    from rovit_hip.losses import JointLoss
+    torch.manual_seed(5)
+    cfg = SimpleNamespace(train=SimpleNamespace(learning_rate=1e-3, weight_decay=1e-4, epochs=10),
+                          flags=SimpleNamespace(gradient_clip=1.0))
+    m = RoViTKAN(pretrained=False, dropout=0.0).to(dev()).train()
+    opt = build_optimizer(m, cfg)
+    assert isinstance(opt, torch.optim.Optimizer) and isinstance(opt, RoViTAdamW)
+    assert [g['lr'] for g in opt.param_groups] == [1e-4, 1e-3] and get_lr(opt) == 1e-4
+    sched = build_scheduler(opt, cfg)
+    x = torch.randn(4, 3, 224, 224, device=dev())
+    y = torch.randint(0, 4, (4,), device=dev())
+    lf = JointLoss()
+
+    def one_step(model, optimizer):
+        optimizer.zero_grad()
+        lf(model(x), y, y, 4)['total_loss'].backward()
+        optimizer.step()
+    one_step(m, opt)
+    sched.step()
+    lrs = [g['lr'] for g in opt.param_groups]
+    assert lrs[0] < 1e-4 and lrs[1] < 1e-3 and abs(lrs[1] / lrs[0] - 10.0) < 0.2       # cosine decay of both groups
+    # resume: clone model + optimizer state, both take one more step -> identical parameters
+    m2 = copy.deepcopy(m)
+    opt2 = build_optimizer(m2, cfg)
+    opt2.load_state_dict(copy.deepcopy(opt.state_dict()))
+    assert [g['lr'] for g in opt2.param_groups] == lrs and opt2.t == opt.t
+    one_step(m, opt)
+    one_step(m2, opt2)
+    for (n, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
+        assert float((p - q).abs().max()) <= 1e-6 * float(p.abs().max() + 1e-12), n

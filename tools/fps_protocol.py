@@ -1,0 +1,23 @@
+"""The reference's `fps()` protocol (evaluation/metrics.py:63-93: batch 1, 10 warm-up, 100 timed forwards, wall clock
+with a device sync) on the HIP path, next to its published 2.6 img/s (CPU, KAN active) / 36.7 img/s figures.
+Also prints batch-256 inference throughput.  Developer tool: python tools/fps_protocol.py"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'rovit-kan-interpretable-vision-transformer-for-rose-disease-severity-estimation_amd'))
+import torch
+from models.rovit_kan import RoViTKAN
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+m = RoViTKAN(pretrained=False).to(dev).eval()
+for B, warm, n in ((1, 10, 100), (256, 5, 30)):
+    x = torch.randn(B, 3, 224, 224, device=dev)
+    with torch.no_grad():
+        for _ in range(warm):
+            m(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            m(x)
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f'batch {B}: {n * B / dt:9.1f} images/s  ({dt / n * 1e3:.3f} ms per forward, stage 4, eval)')

@@ -119,19 +119,21 @@ __global__ __launch_bounds__(256) void kan_fwd_kernel(const float* __restrict__ 
       const int chunk = (in_f + nsplit - 1) / nsplit;
       const int i_lo = part * chunk, i_hi = min(in_f, i_lo + chunk);
       const float* lwo = lw + (size_t)o * in_f;
-#pragma unroll 4
+      // branch-free gathers (clamped index, masked value) so that several features' loads are in flight at once:
+      // the loop is a chain of L2 round trips, not arithmetic
+#pragma unroll 8
       for (int i = i_lo; i < i_hi; ++i) {
         const int q = bl * in_f + i;
-        acc = fmaf(s_x[q], lwo[i], acc);
         const int j = s_j[q];
-        if (j >= 0) {
-          const float4 v = *(const float4*)(s_v + 4 * q);
-          const float* w = W + ((size_t)i * out_f + o) * nb;
-          acc = fmaf(v.x, w[j], acc);
-          if (j >= 1) acc = fmaf(v.y, w[j - 1], acc);
-          if (j >= 2) acc = fmaf(v.z, w[j - 2], acc);
-          if (j >= 3) acc = fmaf(v.w, w[j - 3], acc);
-        }
+        const float4 v = *(const float4*)(s_v + 4 * q);
+        const float* w = W + ((size_t)i * out_f + o) * nb;
+        const int jc = j > 0 ? j : 0;
+        const float w0 = w[jc], w1 = w[jc >= 1 ? jc - 1 : 0], w2 = w[jc >= 2 ? jc - 2 : 0], w3 = w[jc >= 3 ? jc - 3 : 0];
+        acc = fmaf(s_x[q], lwo[i], acc);
+        acc = fmaf(j >= 0 ? v.x : 0.f, w0, acc);
+        acc = fmaf(j >= 1 ? v.y : 0.f, w1, acc);
+        acc = fmaf(j >= 2 ? v.z : 0.f, w2, acc);
+        acc = fmaf(j >= 3 ? v.w : 0.f, w3, acc);
       }
     }
     if (nsplit > 1) {
@@ -177,18 +179,20 @@ __global__ __launch_bounds__(256) void kan_bwd_dx_kernel(const float* __restrict
     const Basis4 bs = kan_basis<true>(xn, s_knots, nk, inv_h0, dv);
     const float* g = s_g + bl * out_f;
     float lin = 0.f, spl = 0.f;
-#pragma unroll 4
-    for (int o = 0; o < out_f; ++o) {
+    const int jc = bs.j > 0 ? bs.j : 0;
+    const int j1 = jc >= 1 ? jc - 1 : 0, j2 = jc >= 2 ? jc - 2 : 0, j3 = jc >= 3 ? jc - 3 : 0;
+    const float d0 = bs.j >= 0 ? dv[0] : 0.f, d1 = bs.j >= 1 ? dv[1] : 0.f, d2 = bs.j >= 2 ? dv[2] : 0.f, d3 = bs.j >= 3 ? dv[3] : 0.f;
+#pragma unroll 8
+    for (int o = 0; o < out_f; ++o) {                     // branch-free: loads of several outputs in flight
       const float go = g[o];
+      const float* w = W + ((size_t)i * out_f + o) * nb;
+      const float w0 = w[jc], w1 = w[j1], w2 = w[j2], w3 = w[j3];
       lin = fmaf(go, lw[(size_t)o * in_f + i], lin);
-      if (bs.j >= 0) {
-        const float* w = W + ((size_t)i * out_f + o) * nb;
-        float s = dv[0] * w[bs.j];
-        if (bs.j >= 1) s = fmaf(dv[1], w[bs.j - 1], s);
-        if (bs.j >= 2) s = fmaf(dv[2], w[bs.j - 2], s);
-        if (bs.j >= 3) s = fmaf(dv[3], w[bs.j - 3], s);
-        spl = fmaf(go, s, spl);
-      }
+      float sv = d0 * w0;
+      sv = fmaf(d1, w1, sv);
+      sv = fmaf(d2, w2, sv);
+      sv = fmaf(d3, w3, sv);
+      spl = fmaf(go, sv, spl);
     }
     const float r = fmaf(spl, 1.f - xn * xn, lin);       // d tanh; clamp is the identity on (-1, 1)
     float* p = dx + (size_t)b * in_f + i;
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(256) void kan_bwd_dx_kernel(const float* __restrict
 }
 
 // backward wrt the parameters: one workgroup = one input feature i (owns dW[i,:,:] and dlin_w[:,i]).
-__global__ __launch_bounds__(256) void kan_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ knots,
+__global__ __launch_bounds__(1024) void kan_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ knots,
                                                          const float* __restrict__ y, const float* __restrict__ gy,
                                                          float* __restrict__ dW, float* __restrict__ dlw,
                                                          float* __restrict__ dlb, int B, int in_f, int out_f, int nk,
@@ -207,7 +211,8 @@ __global__ __launch_bounds__(256) void kan_bwd_dw_kernel(const float* __restrict
   float* s_x = s_knots + KAN_MAX_KNOTS;      // BC
   float* s_d = s_x + BC;                     // BC * nb dense basis of feature i
   float* s_gz = s_d + BC * (nk - 4);         // BC * out_f  dL/dz of this batch chunk (read many times below)
-  const int tid = threadIdx.x;
+  float* s_part = s_gz + BC * out_f;         // blockDim partial sums
+  const int tid = threadIdx.x, T = blockDim.x;
   const int nb = nk - 4;
   const int i = blockIdx.x;
   if (tid < nk) s_knots[tid] = knots[tid];
@@ -215,10 +220,13 @@ __global__ __launch_bounds__(256) void kan_bwd_dw_kernel(const float* __restrict
   const float inv_h0 = 1.f / (s_knots[1] - s_knots[0]);
   const int n_sp = out_f * nb;
   const int n_items = n_sp + out_f + (i == 0 ? out_f : 0);
+  // The sample loop of one item is a serial chain (2 LDS reads + 1 FMA per sample), so when there are fewer items
+  // than threads each item is shared by `nsplit` threads that take a slice of the samples (layer 3 has 9 items).
+  const int nsplit = n_items >= T ? 1 : T / n_items;
   for (int c0 = 0; c0 < B; c0 += BC) {
     const int nbatch = min(BC, B - c0);
     __syncthreads();
-    for (int bl = tid; bl < nbatch; bl += 256) {
+    for (int bl = tid; bl < nbatch; bl += T) {
       const float xv = x[(size_t)(c0 + bl) * in_f + i];
       const Basis4 bs = kan_basis<false>(tanhf(xv), s_knots, nk, inv_h0, nullptr);
       float* row = s_d + bl * nb;
@@ -231,26 +239,63 @@ __global__ __launch_bounds__(256) void kan_bwd_dw_kernel(const float* __restrict
       }
       s_x[bl] = xv;
     }
-#pragma unroll 8
-    for (int e = tid; e < nbatch * out_f; e += 256) {
-      const size_t q = (size_t)c0 * out_f + e;
-      s_gz[e] = act_grad(gy[q], y[q], act);
+    {
+      // dL/dz of the chunk: issue every load of a thread before the first use (latency-, not bandwidth-bound)
+      const int n_e = nbatch * out_f;
+      const size_t q0 = (size_t)c0 * out_f;
+      for (int e0 = tid; e0 < n_e; e0 += T * 8) {
+        float gv[8], yv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * T;
+          const int ec = e < n_e ? e : n_e - 1;
+          gv[u] = gy[q0 + ec]; yv[u] = y[q0 + ec];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * T;
+          if (e < n_e) s_gz[e] = act_grad(gv[u], yv[u], act);
+        }
+      }
     }
     __syncthreads();
-    for (int e = tid; e < n_items; e += 256) {
-      int o, k = -1, kind;                    // kind 0: spline weight, 1: linear weight, 2: linear bias
-      if (e < n_sp) { kind = 0; k = e / out_f; o = e - k * out_f; }
-      else if (e < n_sp + out_f) { kind = 1; o = e - n_sp; }
-      else { kind = 2; o = e - n_sp - out_f; }
-      float acc = 0.f;
-#pragma unroll 8
-      for (int bl = 0; bl < nbatch; ++bl) {
-        const float g = s_gz[bl * out_f + o];
-        const float m = kind == 0 ? s_d[bl * nb + k] : (kind == 1 ? s_x[bl] : 1.f);
-        acc = fmaf(g, m, acc);
+    for (int e0 = 0; e0 < n_items; e0 += T) {
+      const int e = e0 + (nsplit == 1 ? tid : tid % n_items);
+      const int part = nsplit == 1 ? 0 : tid / n_items;
+      const bool live = e < n_items && part < nsplit;
+      int o = 0, k = 0, kind = 2;             // kind 0: spline weight, 1: linear weight, 2: linear bias
+      if (live) {
+        if (e < n_sp) { kind = 0; k = e / out_f; o = e - k * out_f; }
+        else if (e < n_sp + out_f) { kind = 1; o = e - n_sp; }
+        else { kind = 2; o = e - n_sp - out_f; }
       }
-      float* p = kind == 0 ? dW + ((size_t)i * out_f + o) * nb + k : (kind == 1 ? dlw + (size_t)o * in_f + i : dlb + o);
-      *p = c0 == 0 ? acc : *p + acc;
+      float acc = 0.f;
+      if (live) {
+        const int chunk = (nbatch + nsplit - 1) / nsplit;
+        const int lo = part * chunk, hi = min(nbatch, lo + chunk);
+        const float* mp = kind == 0 ? s_d + k : s_x;          // multiplier stream: stride nb (spline) or 1 (linear)
+        const int ms = kind == 0 ? nb : 1;
+        if (kind == 2) {
+#pragma unroll 8
+          for (int bl = lo; bl < hi; ++bl) acc += s_gz[bl * out_f + o];
+        } else {
+#pragma unroll 8
+          for (int bl = lo; bl < hi; ++bl) acc = fmaf(s_gz[bl * out_f + o], mp[bl * ms], acc);
+        }
+      }
+      if (nsplit > 1) {
+        s_part[tid] = acc;
+        __syncthreads();
+        if (live && part == 0) {
+          acc = 0.f;
+          for (int p = 0; p < nsplit; ++p) acc += s_part[p * n_items + e];
+        }
+        __syncthreads();
+      }
+      if (live && part == 0) {
+        float* p = kind == 0 ? dW + ((size_t)i * out_f + o) * nb + k : (kind == 1 ? dlw + (size_t)o * in_f + i : dlb + o);
+        *p = c0 == 0 ? acc : *p + acc;
+      }
     }
   }
 }
@@ -355,7 +400,7 @@ __global__ __launch_bounds__(256) void lin_fwd_batch_kernel(const LinFwdBatch pb
   const float4* xr = (const float4*)(d.x + (size_t)b * d.in_f);
   const float4* wr = (const float4*)(d.w + (size_t)o * d.in_f);
   float acc = d.bias ? d.bias[o] : 0.f;
-#pragma unroll 4
+#pragma unroll 12
   for (int k = 0; k < d.in_f / 4; ++k) {
     const float4 a = xr[k], c = wr[k];
     acc = fmaf(a.x, c.x, acc); acc = fmaf(a.y, c.y, acc); acc = fmaf(a.z, c.z, acc); acc = fmaf(a.w, c.w, acc);
@@ -380,7 +425,7 @@ __global__ __launch_bounds__(256) void lin_bwd_dx_batch_kernel(const LinDxBatch 
   const int b = e / d.in_f, k = e - b * d.in_f;
   float acc = 0.f;
   for (int s = 0; s < d.nsrc; ++s) {
-#pragma unroll 8
+#pragma unroll 16
     for (int o = 0; o < d.out_f[s]; ++o) {
       const size_t q = (size_t)b * d.out_f[s] + o;
       acc = fmaf(clamp_gate(d.g[s][q], d.yc[s], q), d.w[s][(size_t)o * d.in_f + k], acc);
@@ -394,29 +439,38 @@ __global__ __launch_bounds__(256) void lin_bwd_dx_batch_kernel(const LinDxBatch 
 struct LinDwDesc { const float* g; const float* x; const float* yc; float* dw; float* db; int in_f, out_f; };
 struct LinDwBatch { LinDwDesc d[4]; int first[5]; int n, B; };
 
+// One workgroup = 64 consecutive dW elements x 4 batch slices (wave w sums samples w, w+4, ...), partial sums
+// combined through LDS: the sample loop is a chain of dependent global loads, so its length, not the arithmetic, sets
+// the kernel time (62 us with one thread walking all 256 samples).
 __global__ __launch_bounds__(256) void lin_bwd_dw_batch_kernel(const LinDwBatch pb) {
+  __shared__ float s_w[4][64], s_b[4][64];
   int i = 0;
   while (i + 1 < pb.n && (int)blockIdx.x >= pb.first[i + 1]) ++i;
   const LinDwDesc& d = pb.d[i];
-  const int e = ((int)blockIdx.x - pb.first[i]) * 256 + threadIdx.x;
-  if (e >= d.out_f * d.in_f) return;
-  const int o = e / d.in_f, k = e - o * d.in_f;
+  const int el = threadIdx.x & 63, bs = threadIdx.x >> 6;
+  const int e = ((int)blockIdx.x - pb.first[i]) * 64 + el;
+  const bool live = e < d.out_f * d.in_f;
+  const int o = live ? e / d.in_f : 0, k = live ? e - o * d.in_f : 0;
   float acc = 0.f, accb = 0.f;
-#pragma unroll 8
-  for (int b = 0; b < pb.B; ++b) {
+#pragma unroll 16
+  for (int b = bs; b < pb.B; b += 4) {
     const size_t q = (size_t)b * d.out_f + o;
     const float gv = clamp_gate(d.g[q], d.yc, q);
     acc = fmaf(gv, d.x[(size_t)b * d.in_f + k], acc);
     accb += gv;
   }
-  d.dw[e] = acc;
-  if (k == 0) d.db[o] = accb;
+  s_w[bs][el] = acc; s_b[bs][el] = accb;
+  __syncthreads();
+  if (bs == 0 && live) {
+    d.dw[e] = (s_w[0][el] + s_w[1][el]) + (s_w[2][el] + s_w[3][el]);
+    if (k == 0) d.db[o] = (s_b[0][el] + s_b[1][el]) + (s_b[2][el] + s_b[3][el]);
+  }
 }
 
 template <class Batch, class Kernel>
-int launch_lin_batch(Batch& pb, int n, const int* work, Kernel kern, const char* name, hipStream_t st) {
+int launch_lin_batch(Batch& pb, int n, const int* work, Kernel kern, const char* name, hipStream_t st, int per_block = 256) {
   int blocks = 0;
-  for (int i = 0; i < n; ++i) { pb.first[i] = blocks; blocks += (work[i] + 255) / 256; }
+  for (int i = 0; i < n; ++i) { pb.first[i] = blocks; blocks += (work[i] + per_block - 1) / per_block; }
   pb.first[n] = blocks; pb.n = n;
   if (blocks == 0) return ROVIT_OK;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st, pb);
@@ -472,10 +526,12 @@ extern "C" int rovit_kan_layer_bwd(const float* x, const float* spline_w, const 
     const int nb = n_knots - 4;
     int bc = (24 * 1024) / (nb + 1 + out_f);   // batch rows whose basis + dL/dz stay in LDS (<= 96 KB)
     bc = bc > batch ? batch : bc;
-    const size_t lds = (KAN_MAX_KNOTS + (size_t)bc * (nb + 1 + out_f)) * sizeof(float);
+    const int n_items = out_f * (nb + 2);
+    const int threads = n_items >= 512 ? 1024 : 256;         // one or more threads per (output, basis) item
+    const size_t lds = (KAN_MAX_KNOTS + (size_t)bc * (nb + 1 + out_f) + threads) * sizeof(float);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)kan_bwd_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); attr = true; }
-    hipLaunchKernelGGL(kan_bwd_dw_kernel, dim3(in_f), dim3(256), lds, (hipStream_t)stream, x, knots, out, grad_out,
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kan_bwd_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024); attr = true; }
+    hipLaunchKernelGGL(kan_bwd_dw_kernel, dim3(in_f), dim3(threads), lds, (hipStream_t)stream, x, knots, out, grad_out,
                        d_spline_w, d_lin_w, d_lin_b, batch, in_f, out_f, n_knots, bc, act);
     ROVIT_CHECK_LAUNCH("kan_bwd_dw_kernel");
   }
@@ -589,7 +645,7 @@ extern "C" int rovit_heads_bwd(const float* features, const float* const* params
   }
   int rc = launch_lin_batch(dxh, nx, wx, lin_bwd_dx_batch_kernel, "lin_bwd_dx_batch_kernel", st);
   if (rc) return rc;
-  rc = launch_lin_batch(dwo, nw, ww, lin_bwd_dw_batch_kernel, "lin_bwd_dw_batch_kernel", st);
+  rc = launch_lin_batch(dwo, nw, ww, lin_bwd_dw_batch_kernel, "lin_bwd_dw_batch_kernel", st, 64);
   if (rc) return rc;
   // 2) through the first layers: d_features = sum_h dh_h W1_h ; dW1_h = dh_h^T features
   LinDxBatch dxf{}; dxf.B = batch;
@@ -606,5 +662,5 @@ extern "C" int rovit_heads_bwd(const float* features, const float* const* params
   int wf[1] = {batch * embed};
   rc = launch_lin_batch(dxf, 1, wf, lin_bwd_dx_batch_kernel, "lin_bwd_dx_batch_kernel", st);
   if (rc) return rc;
-  return launch_lin_batch(dw1, n1, w1, lin_bwd_dw_batch_kernel, "lin_bwd_dw_batch_kernel", st);
+  return launch_lin_batch(dw1, n1, w1, lin_bwd_dw_batch_kernel, "lin_bwd_dw_batch_kernel", st, 64);
 }

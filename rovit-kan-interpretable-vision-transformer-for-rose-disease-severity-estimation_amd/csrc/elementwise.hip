@@ -168,30 +168,48 @@ __global__ __launch_bounds__(256) void cls_ln_bwd_kernel(const float* __restrict
   }
 }
 
+// Both kernels below sum over the batch: a chain of dependent loads whose LENGTH sets the time, so a workgroup is 64
+// elements x 4 batch slices (one wave per slice), combined through LDS in a fixed order (deterministic).
 // dgamma[d] = sum_b dfeat[b,d] xhat[b,d];  dbeta[d] = sum_b dfeat[b,d]
 __global__ __launch_bounds__(256) void cls_ln_affine_grad_kernel(const float* __restrict__ dfeat, const float* __restrict__ xhat,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int B) {
-  const int d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= D) return;
+  __shared__ float s_g[4][64], s_b[4][64];
+  const int el = threadIdx.x & 63, bs = threadIdx.x >> 6;
+  const int d = blockIdx.x * 64 + el;
   float sg = 0.f, sb = 0.f;
-#pragma unroll 8
-  for (int b = 0; b < B; ++b) {
-    const float g = dfeat[(size_t)b * D + d];
-    sg = fmaf(g, xhat[(size_t)b * D + d], sg); sb += g;
+  if (d < D) {
+#pragma unroll 16
+    for (int b = bs; b < B; b += 4) {
+      const float g = dfeat[(size_t)b * D + d];
+      sg = fmaf(g, xhat[(size_t)b * D + d], sg); sb += g;
+    }
   }
-  dgamma[d] = sg; dbeta[d] = sb;
+  s_g[bs][el] = sg; s_b[bs][el] = sb;
+  __syncthreads();
+  if (bs == 0 && d < D) {
+    dgamma[d] = (s_g[0][el] + s_g[1][el]) + (s_g[2][el] + s_g[3][el]);
+    dbeta[d] = (s_b[0][el] + s_b[1][el]) + (s_b[2][el] + s_b[3][el]);
+  }
 }
 
 // dpos[t,d] = sum_b dX[b,t,d];  dcls[d] = dpos[0,d]
 __global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__ dX, float* __restrict__ dpos,
                                                        float* __restrict__ dcls, int B, int T) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= T * D) return;
+  __shared__ float s_p[4][64];
+  const int el = threadIdx.x & 63, bs = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
   float s = 0.f;
-#pragma unroll 8
-  for (int b = 0; b < B; ++b) s += dX[(size_t)b * T * D + e];
-  dpos[e] = s;
-  if (e < D) dcls[e] = s;
+  if (e < T * D) {
+#pragma unroll 16
+    for (int b = bs; b < B; b += 4) s += dX[(size_t)b * T * D + e];
+  }
+  s_p[bs][el] = s;
+  __syncthreads();
+  if (bs == 0 && e < T * D) {
+    const float t = (s_p[0][el] + s_p[1][el]) + (s_p[2][el] + s_p[3][el]);
+    dpos[e] = t;
+    if (e < D) dcls[e] = t;
+  }
 }
 
 // ---- weight preparation ------------------------------------------------------------------------------------
@@ -336,7 +354,7 @@ extern "C" int rovit_cls_norm_bwd(const float* dfeat, const float* xhat, const f
                      (bf16*)dXb, batch, tokens);
   ROVIT_CHECK_LAUNCH("cls_ln_bwd_kernel");
   if (dgamma) {
-    hipLaunchKernelGGL(cls_ln_affine_grad_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dfeat, xhat, dgamma, dbeta, batch);
+    hipLaunchKernelGGL(cls_ln_affine_grad_kernel, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)stream, dfeat, xhat, dgamma, dbeta, batch);
     ROVIT_CHECK_LAUNCH("cls_ln_affine_grad_kernel");
   }
   return ROVIT_OK;
@@ -344,7 +362,7 @@ extern "C" int rovit_cls_norm_bwd(const float* dfeat, const float* xhat, const f
 
 extern "C" int rovit_pos_grad(const float* dX, float* dpos, float* dcls, int batch, int tokens, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(dX && dpos && dcls, ROVIT_ERR_NULL, "pos_grad: null pointer");
-  hipLaunchKernelGGL(pos_grad_kernel, dim3((tokens * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dX, dpos, dcls, batch, tokens);
+  hipLaunchKernelGGL(pos_grad_kernel, dim3((tokens * D + 63) / 64), dim3(256), 0, (hipStream_t)stream, dX, dpos, dcls, batch, tokens);
   ROVIT_CHECK_LAUNCH("pos_grad_kernel");
   return ROVIT_OK;
 }

@@ -80,7 +80,7 @@ extern "C" int rovit_sq_norm_accum(const float* g, size_t n, float* out_sq, rovi
   ROVIT_CHECK_ARG(rovit_aligned16(g), ROVIT_ERR_ALIGN, "sq_norm_accum: gradient buffer must be 16-byte aligned");
   if (n == 0) return ROVIT_OK;
   size_t blocks = (n / 4 + 255) / 256;
-  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);      // one atomic per block onto a single address
   hipLaunchKernelGGL(sq_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out_sq);
   ROVIT_CHECK_LAUNCH("sq_norm_kernel");
   return ROVIT_OK;

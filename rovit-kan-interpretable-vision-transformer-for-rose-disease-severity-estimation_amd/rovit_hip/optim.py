@@ -120,8 +120,9 @@ class RoViTAdamW(torch.optim.Optimizer):
             self._sq.zero_()
             if bb:
                 call('rovit_sq_norm_accum', ptr(eng.grad_flat), eng.grad_flat.numel(), ptr(self._sq), sp)
-            for s in active:            # padding floats of o_grad stay zero, so whole aligned segments can be summed
-                call('rovit_sq_norm_accum', ptr(self.o_grad[s.offset:]), (s.numel + 3) // 4 * 4, ptr(self._sq), sp)
+            for first, last in self._runs(active):      # padding floats of o_grad stay zero: sum whole aligned runs
+                call('rovit_sq_norm_accum', ptr(self.o_grad[first.offset:]),
+                     last.offset + (last.numel + 3) // 4 * 4 - first.offset, ptr(self._sq), sp)
             call('rovit_clip_coef', ptr(self._sq), float(self.max_grad_norm), ptr(self._coef), ptr(self._norm), sp)
             self.last_grad_norm = self._norm
             coef = ptr(self._coef)
@@ -131,21 +132,27 @@ class RoViTAdamW(torch.optim.Optimizer):
                  self.p_flat.numel(), coef, float(gb['lr']), gb['betas'][0], gb['betas'][1], gb['eps'], gb['weight_decay'], self.t, sp)
             eng._prep_key = None            # parameters changed behind torch's version counters: re-prepare weights
         # consecutive active segments with the same step count share one launch (the usual case: all of them)
-        i = 0
-        while i < len(active):
-            j = i
-            while (j + 1 < len(active) and active[j + 1].t == active[i].t and
-                   active[j + 1].offset == active[j].offset + (active[j].numel + 3) // 4 * 4):
-                j += 1
-            first, last = active[i], active[j]
+        for first, last in self._runs(active, same_t=True):
             n = last.offset + last.numel - first.offset
-            for s in active[i:j + 1]:
+            for s in active[active.index(first):active.index(last) + 1]:
                 s.t += 1
             o = first.offset
             call('rovit_adamw_flat', ptr(self.o_flat[o:]), ptr(self.o_grad[o:]), ptr(self.o_m[o:]), ptr(self.o_v[o:]), n, coef,
                  float(gh['lr']), gh['betas'][0], gh['betas'][1], gh['eps'], gh['weight_decay'], first.t, sp)
-            i = j + 1
         return loss
+
+    @staticmethod
+    def _runs(active, same_t: bool = False):
+        """(first, last) of every run of segments that are adjacent in the flat buffer (and share a step count)."""
+        runs, i = [], 0
+        while i < len(active):
+            j = i
+            while (j + 1 < len(active) and (not same_t or active[j + 1].t == active[i].t) and
+                   active[j + 1].offset == active[j].offset + (active[j].numel + 3) // 4 * 4):
+                j += 1
+            runs.append((active[i], active[j]))
+            i = j + 1
+        return runs
 
     def state_dict(self):
         """param_groups as torch reports them + the flat moment buffers and step counts."""

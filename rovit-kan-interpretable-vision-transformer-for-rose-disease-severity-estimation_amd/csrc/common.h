@@ -126,7 +126,7 @@ struct RovitPrepDesc {
   void* Wf; void* WfT; float* bias_f;
   int N, K;
 };
-constexpr int ROVIT_PREP_BATCH = 24;
+constexpr int ROVIT_PREP_BATCH = 52;     // 1 + 4*12 descriptors of a depth-12 backbone in ONE launch (3.5 KB of kernel arguments)
 int rovit_prep_weight_batch(const RovitPrepDesc* descs, int n, rovit_stream_t stream);
 
 // LayerNorm forward / backward on every row_step-th row of the dense (rows*row_step, 192) buffers, in place

@@ -66,3 +66,30 @@ def test_full_model_step_is_reproducible_at_batch_256():
         else:
             assert torch.equal(fi, ref[0]) and torch.equal(f.detach(), ref[0]), rep
             assert torch.equal(g, ref[1]), rep
+
+
+@pytest.mark.parametrize('B', [16, 31, 33, 100, 255])
+def test_two_stream_forward_equals_small_batch_chunks(B):
+    """Batches >= 16 run as two half-batch chains on two streams; batches < 16 run on one.  Samples are independent,
+    so the big-batch features must equal, bit for bit, the features of the same images pushed through in chunks of 8
+    (any cross-stream ordering bug or row-offset mistake shows up as a difference), and the gradients of a sum-type
+    loss must equal the sum of the chunk gradients (different summation order: 2e-3 of the largest entry)."""
+    from models.backbone import DeiTTiny
+    torch.manual_seed(B)
+    m = DeiTTiny(3).to(dev())
+    x = torch.randn(B, 3, 224, 224, device=dev())
+    w = torch.randn(B, 192, device=dev())
+    f = m(x)
+    (f * w).sum().backward()
+    g_big = {n: p.grad.clone() for n, p in m.named_parameters()}
+    for p in m.parameters():
+        p.grad = None
+    feats = []
+    for i in range(0, B, 8):
+        fc = m(x[i:i + 8])
+        (fc * w[i:i + 8]).sum().backward()                   # accumulates into the engine-owned gradients
+        feats.append(fc.detach())
+    assert torch.equal(f.detach(), torch.cat(feats))
+    for n, p in m.named_parameters():
+        scale = float(g_big[n].abs().max()) + 1e-12
+        assert float((p.grad - g_big[n]).abs().max()) <= 2e-3 * scale, n

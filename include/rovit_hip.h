@@ -98,9 +98,10 @@ int rovit_vit_forward(const float* images, const float* const* params, const voi
                       int batch, int depth, int training, rovit_stream_t stream);
 /* forward + explainability taps: attn_taps is a HOST array of `depth` device pointers (bf16 (B*197,192)) that receive
  * each block's attention-module output -- what DeiTTinyBackbone.get_attention_maps collects through forward hooks on
- * `blocks[i].attn` (models/backbone.py:37-62).  Uses the inference workspace. */
+ * `blocks[i].attn` (models/backbone.py:37-62).  prob_taps (optional, like attn_taps): fp32 (B,3,197,197) softmax
+ * probabilities per block, what explainability/attention_maps.py:18-105 means to roll out.  Inference workspace. */
 int rovit_vit_forward_taps(const float* images, const float* const* params, const void* prep, void* workspace, float* features,
-                           void* const* attn_taps, int batch, int depth, rovit_stream_t stream);
+                           void* const* attn_taps, float* const* prob_taps, int batch, int depth, rovit_stream_t stream);
 int rovit_vit_backward(const float* d_features, const float* const* params, const void* prep, void* workspace,
                        float* const* grads, int batch, int depth, int first_block, int last_block, rovit_stream_t stream);
 /* rovit_vit_backward for a data-parallel caller: for last_block > 0 the call does not wait for the range's weight
@@ -139,6 +140,9 @@ int rovit_wgrad_reduce(const float* ws, int splits, int N, int K, const float* g
  * lse2 (B,H,T) = log2 sum exp(scale q.k) */
 int rovit_attention_fwd(const void* qkv, void* out, float* lse2, int batch, int tokens, int heads, int head_dim, float scale,
                         rovit_stream_t stream);
+/* softmax(scale q k^T) as fp32 (B,H,T,T) from a saved qkv tensor -- explainability only */
+int rovit_attention_probs(const void* qkv, float* probs, int batch, int tokens, int heads, int head_dim, float scale,
+                          rovit_stream_t stream);
 int rovit_attention_bwd(const void* qkv, const void* out, const float* lse2, const void* dout, void* dqkv, int batch, int tokens,
                         int heads, int head_dim, float scale, rovit_stream_t stream);
 int rovit_layernorm_fwd(const float* x, void* xhat, float* rstd, int rows, int dim, float eps, rovit_stream_t stream);

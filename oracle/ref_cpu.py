@@ -263,7 +263,8 @@ def init_vit_state(depth: int = VIT_DEPTH, generator: Optional[torch.Generator] 
 
 
 def vit_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str = '', heads: int = VIT_HEADS,
-                eps: float = 1e-6, return_tokens: bool = False, attn_taps: Optional[list] = None):
+                eps: float = 1e-6, return_tokens: bool = False, attn_taps: Optional[list] = None,
+                attn_probs: Optional[list] = None):
     """timm VisionTransformer.forward for deit_tiny_patch16_224, num_classes=0:
     patch conv k16/s16 -> [cls | patches] + pos_embed -> 12 pre-norm blocks -> LayerNorm -> token 0."""
     B = x.shape[0]
@@ -280,6 +281,8 @@ def vit_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str = '', 
         qkv = qkv.reshape(B, -1, 3, heads, hd).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
         a = torch.softmax((q * hd ** -0.5) @ k.transpose(-2, -1), dim=-1)
+        if attn_probs is not None:
+            attn_probs.append(a)                                       # (B, heads, N, N) softmax probabilities
         o = (a @ v).transpose(1, 2).reshape(B, -1, dim)
         ao = F.linear(o, sd[b + 'attn.proj.weight'], sd[b + 'attn.proj.bias'])
         if attn_taps is not None:                                      # what a forward hook on blocks[i].attn sees

@@ -341,7 +341,56 @@ int check_attn(int batch, int tokens, int heads, int head_dim) {
   return ROVIT_OK;
 }
 
+// Explainability only (not on the training path): the softmax probabilities themselves, fp32 (B,H,T,T), from a saved
+// qkv tensor.  One wave per query row; lanes stride over the keys.
+__global__ __launch_bounds__(256) void attn_probs_kernel(const bf16* __restrict__ qkv, float* __restrict__ probs, int B, int T, int H,
+                                                         int HD, float scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);          // (b, h, q)
+  const int lane = threadIdx.x & 63;
+  if (row >= B * H * T) return;
+  const int q = row % T, h = (row / T) % H, b = row / (T * H);
+  const int ld = 3 * H * HD;
+  const bf16* qp = qkv + ((size_t)b * T + q) * ld + h * HD;
+  float s[4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int key = lane + 64 * u;
+    s[u] = -INFINITY;
+    if (key < T) {
+      const bf16* kp = qkv + ((size_t)b * T + key) * ld + H * HD + h * HD;
+      float acc = 0.f;
+      for (int d = 0; d < HD; ++d) acc = fmaf((float)qp[d], (float)kp[d], acc);
+      s[u] = acc * scale;
+      mx = fmaxf(mx, s[u]);
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { s[u] = lane + 64 * u < T ? __expf(s[u] - mx) : 0.f; sum += s[u]; }
+  sum = wave_sum64(sum);
+  const float inv = 1.f / sum;
+  float* out = probs + (size_t)row * T;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (lane + 64 * u < T) out[lane + 64 * u] = s[u] * inv;
+}
+
 }  // namespace
+
+extern "C" int rovit_attention_probs(const void* qkv, float* probs, int batch, int tokens, int heads, int head_dim, float scale,
+                                     rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(qkv && probs, ROVIT_ERR_NULL, "attention_probs: null pointer");
+  ROVIT_CHECK_ARG(batch > 0 && tokens > 0 && tokens <= 256 && heads > 0 && head_dim > 0, ROVIT_ERR_SHAPE,
+                  "attention_probs: unsupported shape (tokens <= 256)");
+  const int rows = batch * heads * tokens;
+  hipLaunchKernelGGL(attn_probs_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, probs, batch, tokens,
+                     heads, head_dim, scale);
+  ROVIT_CHECK_LAUNCH("attn_probs_kernel");
+  return ROVIT_OK;
+}
 
 extern "C" int rovit_attention_fwd(const void* qkv, void* out, float* lse2, int batch, int tokens, int heads, int head_dim,
                                    float scale, rovit_stream_t stream) {

@@ -203,7 +203,7 @@ extern "C" int rovit_vit_prepare(const float* const* params, void* prep, int dep
 
 namespace {
 int vit_forward_impl(const float* images, const float* const* params, const void* prep, void* workspace, float* features,
-                     void* const* attn_taps, int batch, int depth, int training, rovit_stream_t stream) {
+                     void* const* attn_taps, float* const* prob_taps, int batch, int depth, int training, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(images && features, ROVIT_ERR_NULL, "vit_forward: null images/features");
   RUN(check_common(params, prep, workspace, batch, depth));
   const Prep P(depth);
@@ -222,7 +222,7 @@ int vit_forward_impl(const float* images, const float* const* params, const void
   // persistent launch with ~6 us of ramp (dispatch, weight prologue, first tile, tail), which the other half's
   // kernels now cover.  Each half asks for half of the CUs (rovit_set_cu_budget) so the two chains co-reside.
   static const bool fwd_split = !getenv("ROVIT_FWD_SINGLE");
-  SideStream* ss = (two_streams_enabled() && fwd_split && !attn_taps && batch >= 16) ? side_stream() : nullptr;
+  SideStream* ss = (two_streams_enabled() && fwd_split && !attn_taps && !prob_taps && batch >= 16) ? side_stream() : nullptr;
   struct Half { int b0, nb; rovit_stream_t st; };
   Half halves[2] = {{0, ss ? (batch + 1) / 2 : batch, stream}, {(batch + 1) / 2, ss ? batch / 2 : 0, ss ? (rovit_stream_t)ss->stream : stream}};
   if (ss && getenv("ROVIT_DBG_SAME_STREAM")) halves[1].st = stream;
@@ -266,6 +266,9 @@ int vit_forward_impl(const float* images, const float* const* params, const void
     if (attn_taps && attn_taps[i])
       RUN(rovit_gemm_nt(s + L.o, D, q + P.wproj, D, M, D, D, bp[B_PROJB], EPI_BF16, attn_taps[i], D, nullptr, nullptr, 0, nullptr, 0,
                         nullptr, 0, stream));
+    // ... and, separately, the softmax probabilities (B,3,197,197) the reference's rollout code means to collect
+    // (explainability/attention_maps.py:18-105)
+    if (prob_taps && prob_taps[i]) RUN(rovit_attention_probs(s + L.qkv, prob_taps[i], batch, T, H, D / H, 0.125f, stream));
     EACH_HALF {
       const Half& h = halves[hh];
       float* Xh = X + (size_t)h.b0 * T * D;
@@ -309,15 +312,17 @@ int vit_forward_impl(const float* images, const float* const* params, const void
 // images fp32 NCHW (B,3,224,224) -> features fp32 (B,192)
 extern "C" int rovit_vit_forward(const float* images, const float* const* params, const void* prep, void* workspace,
                                  float* features, int batch, int depth, int training, rovit_stream_t stream) {
-  return vit_forward_impl(images, params, prep, workspace, features, nullptr, batch, depth, training, stream);
+  return vit_forward_impl(images, params, prep, workspace, features, nullptr, nullptr, batch, depth, training, stream);
 }
 
 // Same forward (inference workspace), additionally writing each block's attention-module output into
-// attn_taps[i] (bf16, (B*197,192)); NULL entries are skipped.
+// attn_taps[i] (bf16, (B*197,192)) and/or its softmax probabilities into prob_taps[i] (fp32, (B,3,197,197)); either
+// array may be NULL, NULL entries are skipped.
 extern "C" int rovit_vit_forward_taps(const float* images, const float* const* params, const void* prep, void* workspace,
-                                      float* features, void* const* attn_taps, int batch, int depth, rovit_stream_t stream) {
-  ROVIT_CHECK_ARG(attn_taps, ROVIT_ERR_NULL, "vit_forward_taps: null tap array");
-  return vit_forward_impl(images, params, prep, workspace, features, attn_taps, batch, depth, 0, stream);
+                                      float* features, void* const* attn_taps, float* const* prob_taps, int batch, int depth,
+                                      rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(attn_taps || prob_taps, ROVIT_ERR_NULL, "vit_forward_taps: no tap array given");
+  return vit_forward_impl(images, params, prep, workspace, features, attn_taps, prob_taps, batch, depth, 0, stream);
 }
 
 // Backward over blocks first_block, first_block-1, ..., last_block (inclusive).  first_block == depth-1 also

@@ -137,6 +137,11 @@ class DeiTTinyBackbone(nn.Module):
         from rovit_hip import taps
         return taps.attention_outputs(self.model, x)
 
+    def get_attention_probabilities(self, x: torch.Tensor):
+        """Extension (not in the reference): the softmax probabilities (B,3,197,197) per block, for attention rollout."""
+        from rovit_hip import taps
+        return taps.attention_probabilities(self.model, x)
+
 
 def freeze_backbone(model: nn.Module, freeze: bool = True):
     if not hasattr(model, 'backbone'):

@@ -34,7 +34,8 @@ SIGNATURES = {
     'rovit_vit_workspace_bytes': (_sz, [_i, _i, _i]),
     'rovit_vit_prepare': (_i, [_vp, _vp, _i, _vp]),
     'rovit_vit_forward': (_i, [_vp] * 5 + [_i] * 3 + [_vp]),
-    'rovit_vit_forward_taps': (_i, [_vp] * 6 + [_i, _i, _vp]),
+    'rovit_vit_forward_taps': (_i, [_vp] * 7 + [_i, _i, _vp]),
+    'rovit_attention_probs': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     'rovit_vit_backward': (_i, [_vp] * 5 + [_i] * 4 + [_vp]),
     'rovit_vit_backward_notify': (_i, [_vp] * 5 + [_i] * 4 + [_vp] + [_vp]),
     'rovit_gemm_nt': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),

@@ -21,7 +21,26 @@ def attention_outputs(model, x: torch.Tensor) -> List[torch.Tensor]:
     feats = torch.empty(B, 192, device=x.device, dtype=torch.float32)
     taps = [torch.empty(B * 197, 192, device=x.device, dtype=torch.bfloat16) for _ in range(eng.depth)]
     with torch.no_grad():
-        call('rovit_vit_forward_taps', ptr(x), ptr_array(params), ptr(eng.prep), ptr(ws), ptr(feats), ptr_array(taps), B, eng.depth,
-             stream_ptr())
+        call('rovit_vit_forward_taps', ptr(x), ptr_array(params), ptr(eng.prep), ptr(ws), ptr(feats), ptr_array(taps), None, B,
+             eng.depth, stream_ptr())
     eng.give_ws(B, False, ws)
     return [t.float().view(B, 197, 192) for t in taps]
+
+
+def attention_probabilities(model, x: torch.Tensor) -> List[torch.Tensor]:
+    """The softmax attention probabilities of every block, (B, 3, 197, 197) fp32 -- what the reference's rollout code
+    (explainability/attention_maps.py:18-105) means to collect from its hooks (current timm no longer returns them,
+    SURVEY.md 8(a) row a4 / 8(f) row f-4).  ``model`` is the DeiTTiny parameter container (``backbone.model``)."""
+    x = x.float().contiguous()
+    params = model.ordered_parameters()
+    eng = model.engine
+    eng.prepare(params)
+    B = x.shape[0]
+    ws = eng.take_ws(B, False, x.device)
+    feats = torch.empty(B, 192, device=x.device, dtype=torch.float32)
+    probs = [torch.empty(B, 3, 197, 197, device=x.device, dtype=torch.float32) for _ in range(eng.depth)]
+    with torch.no_grad():
+        call('rovit_vit_forward_taps', ptr(x), ptr_array(params), ptr(eng.prep), ptr(ws), ptr(feats), None, ptr_array(probs), B,
+             eng.depth, stream_ptr())
+    eng.give_ws(B, False, ws)
+    return probs

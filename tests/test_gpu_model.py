@@ -476,3 +476,26 @@ def test_optimizer_is_a_torch_optimizer_scheduler_and_state_dict_round_trip():
     one_step(m2, opt2)
     for (n, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
         assert float((p - q).abs().max()) <= 1e-6 * float(p.abs().max() + 1e-12), n
+
+
+def test_attention_probability_taps_vs_oracle():
+    """Softmax probabilities per block (B,3,197,197): rows sum to 1, and match the oracle within the bf16 tolerance of
+    the q/k operands (probabilities are <= 1; measured max |diff| ~1e-3 at init scale)."""
+    from models.backbone import DeiTTinyBackbone
+    depth, B = 3, 2
+    gen = torch.Generator().manual_seed(41)
+    sd = ref_cpu.init_vit_state(depth, gen)
+    x = torch.randn(B, 3, 224, 224, generator=gen)
+    ref_p = []
+    with torch.no_grad():
+        ref_cpu.vit_forward(x, sd, attn_probs=ref_p)
+    bb = DeiTTinyBackbone(pretrained=False)
+    bb.model = bb.model.__class__(depth)
+    bb.model.load_state_dict(sd)
+    bb = bb.to(dev())
+    probs = bb.get_attention_probabilities(x.to(dev()))
+    assert len(probs) == depth
+    for i, (p, r) in enumerate(zip(probs, ref_p)):
+        assert p.shape == (B, 3, 197, 197) and p.dtype == torch.float32
+        assert float((p.sum(-1) - 1).abs().max()) < 1e-5
+        assert float((p.cpu() - r).abs().max()) < 5e-3, i

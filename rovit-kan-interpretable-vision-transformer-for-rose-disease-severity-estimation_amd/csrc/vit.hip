@@ -363,6 +363,9 @@ int vit_backward_impl(const float* d_features, const float* const* params, const
   hipStream_t sA = (hipStream_t)stream;
   SideStream* ss = two_streams_enabled() ? side_stream() : nullptr;
   hipStream_t sB = ss ? ss->stream : sA;
+  static const int bwd_budget = getenv("ROVIT_BWD_BUDGET") ? atoi(getenv("ROVIT_BWD_BUDGET")) : 256;   // developer knob
+  if (ss && bwd_budget != 256) rovit_set_cu_budget(bwd_budget);
+  struct BudgetReset { bool on; ~BudgetReset() { if (on) rovit_set_cu_budget(256); } } budget_reset{ss && bwd_budget != 256};
   static hipEvent_t no_events[64];
   if (ss && !(ss->carry && first_block != depth - 1)) {      // a new backward pass, or the previous range was joined
     ss->next = 0;

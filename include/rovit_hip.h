@@ -127,7 +127,9 @@ int rovit_gemm_resid_ln(const void* A, int lda, const void* W, int ldw, int M, i
  * dxhat = dY W^T;  dX += rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat));  dXb = bf16(dX) */
 int rovit_gemm_ln_bwd(const void* dY, int ldy, const void* W, int ldw, int M, int K, const void* xhat, const float* rstd, float* dX,
                       void* dXb, rovit_stream_t stream);
-int rovit_set_gemm_debug(int flags); /* developer knob: bit 0 skips the epilogue stores (timing experiments) */
+int rovit_set_gemm_debug(int flags); /* developer knob for timing ablations (tools/exp_*.py): bit 0 skip epilogue stores, bit 1 skip
+                                       MFMAs, bit 2 skip steady-state LDS-DMA loads, bit 3 skip the GELU math; bits 4-5 = bits 0-1
+                                       for the weight-gradient kernel.  Results are wrong with any bit set. */
 int rovit_set_gemm_tile(int tile); /* tuning knob: 0 = 128x192 tiles where N allows, 1 = 128x96 */
 /* G(N,K) = dY(M,N)^T A(M,K) and colsum(dY), split over M into `splits` fp32 slabs inside ws */
 int rovit_wgrad_splits(int M, int N, int K);

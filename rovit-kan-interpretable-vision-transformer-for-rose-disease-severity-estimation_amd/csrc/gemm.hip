@@ -33,7 +33,7 @@ struct GemmArgs {
   const float* pos; int tokens;
   int n_tiles;
   float* rstd_out; float eps;   // EPI_RESID_LN: statistics of the LayerNorm fused behind the residual add
-  int dbg;            // developer knob (bit 0: skip epilogue stores, bit 1: skip MFMAs)
+  int dbg;            // developer knob, see rovit_set_gemm_debug (bit 0 skip epilogue stores, 1 skip MFMAs, 2 skip DMA, 3 skip GELU)
 };
 
 // GELU (exact-erf form) and its derivative from ONE exponential: with z = |x|/sqrt(2), e = exp(-z^2) = exp(-x^2/2),
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_dma_kernel(const GemmArgs g, i
   const int tile0 = p * tiles_per_wg;
   int ntile = n_tiles_m - tile0;
   ntile = ntile > tiles_per_wg ? tiles_per_wg : ntile;
-  if (ntile <= 0 || (g.dbg & 16)) return;
+  if (ntile <= 0) return;
   const int n0 = chunk * 192;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -616,8 +616,6 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_dma_kernel(const GemmArgs g, i
   // staged-output tile (aliases the consumed slot): 8-byte write of this lane, 16-byte read-back chunks
   const int cw_row = l15, cw_swz = l15 & 7;
 
-  if (g.dbg & 32) ntile = 1;
-  if (g.dbg & 64) { wait_vmcnt<0>(); if (wf[0][0][0] == (bf16)123.f && bias4[0][0] == 7.f) g.out[0] = wf[1][1][1]; return; }
   for (int t = 0; t < ntile; ++t) {
     const int slot = t % 3;
     // tile t has landed once at most (DMA(t+1..) + this tile's predecessors' stores) are outstanding

@@ -14,8 +14,8 @@ for name, N, K, epi in (('qkv', 576, 192, 0), ('fc1 gelu', 768, 192, 1), ('proj 
         native.call('rovit_gemm_nt', native.ptr(A), K, native.ptr(W), K, M, N, K, native.ptr(bias), epi, native.ptr(out), N, native.ptr(out2) if epi == 1 else None,
                     None, N, None, N, None, 0, sp)
     r = {}
-    for d in (0, 7, 16, 64, 32, 32 + 7):
+    for d in (0, 1, 2, 4, 8, 3, 7, 15):
         native.call('rovit_set_gemm_debug', d)
         r[d] = timeit(run, 20)
     native.call('rovit_set_gemm_debug', 0)
-    print(f'{name:10s} ' + '  '.join(f'dbg{d}:{v:5.1f}' for d, v in r.items()) + '   (7=skeleton 16=empty kernel 64=prologue only 32=one tile only)', flush=True)
+    print(f'{name:10s} ' + '  '.join(f'dbg{d}:{v:5.1f}' for d, v in r.items()) + '   (1=no store 2=no mfma 4=no dma 8=no gelu)', flush=True)

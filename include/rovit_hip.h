@@ -173,10 +173,12 @@ int rovit_mix_images(const float* images, float* out, const long long* perm, int
  * Optimizer step on flat fp32 buffers: global-norm clipping + AdamW as the reference applies them
  * (training/trainer.py:123-128,137-141 clip_grad_norm_(1.0); training/optimizer.py:7-32 AdamW).
  * rovit_sq_norm_accum: *out_sq += sum g^2 (caller zeroes out_sq; several buffers may accumulate into one norm).
+ *   scratch: NULL, or >= 520 floats zeroed ONCE by the caller and then owned by this function (block partials are then
+ *   combined in a fixed order: bit-reproducible; with NULL they are combined with float atomics).
  * rovit_adamw_flat: torch.optim.AdamW semantics; grad_scale = device scalar multiplied into g (clip coefficient)
  * or NULL; t = 1-based step count for the bias correction.
  * ------------------------------------------------------------------------------------------------------------ */
-int rovit_sq_norm_accum(const float* g, size_t n, float* out_sq, rovit_stream_t stream);
+int rovit_sq_norm_accum(const float* g, size_t n, float* out_sq, float* scratch, rovit_stream_t stream);
 /* clip_grad_norm_ coefficient on the device: *norm_out = sqrt(*sq) (optional), *coef = min(1, max_norm / (norm + 1e-6)) */
 int rovit_clip_coef(const float* sq, float max_norm, float* coef, float* norm_out, rovit_stream_t stream);
 int rovit_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, const float* grad_scale, float lr, float beta1,

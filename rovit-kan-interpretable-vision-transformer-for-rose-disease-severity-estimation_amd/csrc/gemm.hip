@@ -930,7 +930,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBat
     for (int j = 0; j < d.splits; ++j) cb += colsum[(size_t)j * d.N + q];
     d.db[q] = cb;
   }
-  if (d.gamma && q < d.K) { d.dgamma[q] = 0.f; d.dbeta[q] = 0.f; }     // accumulated by the affine kernel
 }
 
 constexpr int AFFINE_SLICES = 8;
@@ -962,9 +961,26 @@ __global__ __launch_bounds__(256) void wgrad_affine_batch_kernel(const ReduceBat
   if (grp == 0 && k < d.K) {
 #pragma unroll
     for (int j = 1; j < 8; ++j) { sg += s_g[j][kc]; sb += s_b[j][kc]; }
-    atomicAdd(d.dgamma + k, sg);                         // AFFINE_SLICES partial sums per column; zeroed by the reduce kernel
-    atomicAdd(d.dbeta + k, sb);
+    // AFFINE_SLICES partial sums per column, combined in slice order by the finalize kernel (deterministic: no
+    // float atomics).  Scratch = the head of the slab workspace, which the reduce kernel has finished reading.
+    float* part = const_cast<float*>(d.ws);
+    part[(size_t)sl * d.K + k] = sg;
+    part[(size_t)(AFFINE_SLICES + sl) * d.K + k] = sb;
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_affine_finalize_kernel(const ReduceBatch rb) {
+  int i = 0;
+  while (i + 1 < rb.n && (int)blockIdx.x >= rb.first_block[i + 1]) ++i;
+  const RovitReduceDesc& d = rb.d[i];
+  const int k = ((int)blockIdx.x - rb.first_block[i]) * 256 + threadIdx.x;
+  if (k >= d.K) return;
+  const float* part = d.ws;
+  float sg = 0.f, sb = 0.f;
+#pragma unroll
+  for (int sl = 0; sl < AFFINE_SLICES; ++sl) { sg += part[(size_t)sl * d.K + k]; sb += part[(size_t)(AFFINE_SLICES + sl) * d.K + k]; }
+  d.dgamma[k] = sg;
+  d.dbeta[k] = sb;
 }
 
 }  // namespace
@@ -1079,6 +1095,12 @@ int rovit_wgrad_reduce_batch(const RovitReduceDesc* descs, int n, rovit_stream_t
   if (ab.n > 0) {
     hipLaunchKernelGGL(wgrad_affine_batch_kernel, dim3(ablocks), dim3(256), 0, (hipStream_t)stream, ab);
     ROVIT_CHECK_LAUNCH("wgrad_affine_batch_kernel");
+    ReduceBatch fb = ab;
+    int fblocks = 0;
+    for (int i = 0; i < fb.n; ++i) { fb.first_block[i] = fblocks; fblocks += (fb.d[i].K + 255) / 256; }
+    fb.first_block[fb.n] = fblocks;
+    hipLaunchKernelGGL(wgrad_affine_finalize_kernel, dim3(fblocks), dim3(256), 0, (hipStream_t)stream, fb);
+    ROVIT_CHECK_LAUNCH("wgrad_affine_finalize_kernel");
   }
   return ROVIT_OK;
 }

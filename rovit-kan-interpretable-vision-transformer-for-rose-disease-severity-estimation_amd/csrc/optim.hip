@@ -9,8 +9,13 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void sq_norm_kernel(const float* __restrict__ g, size_t n, float* __restrict__ out) {
+// scratch (optional): [0] ticket counter (as unsigned, left at 0), [8 .. 8+gridDim) per-block partial sums.  With a
+// scratch buffer the block partials are added in block order by the block that finishes last, so the result does not
+// depend on scheduling (bit-reproducible training steps); without it they are added with float atomics.
+__global__ __launch_bounds__(256) void sq_norm_kernel(const float* __restrict__ g, size_t n, float* __restrict__ out,
+                                                      float* __restrict__ scratch) {
   __shared__ float s_part[4];
+  __shared__ bool s_last;
   float acc = 0.f;
   const size_t n4 = n / 4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -21,7 +26,30 @@ __global__ __launch_bounds__(256) void sq_norm_kernel(const float* __restrict__ 
   acc = wave_sum64(acc);
   if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+  if (!scratch) {
+    if (threadIdx.x == 0) atomicAdd(out, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+    return;
+  }
+  if (threadIdx.x == 0) {
+    scratch[8 + blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    __threadfence();
+    const unsigned ticket = atomicAdd((unsigned*)scratch, 1u);
+    s_last = ticket == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_last) {                                   // block-uniform
+    __threadfence();
+    float t = 0.f;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) t += __builtin_nontemporal_load(scratch + 8 + b);
+    // fixed-shape tree over (thread, wave): independent of which block came last
+    t = wave_sum64(t);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      *out += (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+      *(unsigned*)scratch = 0u;                   // ready for the next call on this stream
+    }
+  }
 }
 
 // p, g, m, v: n floats.  grad_scale: device scalar multiplied into g (the clip coefficient), or NULL.
@@ -75,13 +103,13 @@ extern "C" int rovit_clip_coef(const float* sq, float max_norm, float* coef, flo
 }
 
 // out_sq (device scalar) += sum g^2 ; the caller zeroes it (so several buffers can accumulate into one norm)
-extern "C" int rovit_sq_norm_accum(const float* g, size_t n, float* out_sq, rovit_stream_t stream) {
+extern "C" int rovit_sq_norm_accum(const float* g, size_t n, float* out_sq, float* scratch, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(g && out_sq, ROVIT_ERR_NULL, "sq_norm_accum: null pointer");
   ROVIT_CHECK_ARG(rovit_aligned16(g), ROVIT_ERR_ALIGN, "sq_norm_accum: gradient buffer must be 16-byte aligned");
   if (n == 0) return ROVIT_OK;
   size_t blocks = (n / 4 + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);      // one atomic per block onto a single address
-  hipLaunchKernelGGL(sq_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out_sq);
+  hipLaunchKernelGGL(sq_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out_sq, scratch);
   ROVIT_CHECK_LAUNCH("sq_norm_kernel");
   return ROVIT_OK;
 }

@@ -59,7 +59,7 @@ SIGNATURES = {
     'rovit_prep_weight': (_i, [_vp] * 7 + [_i, _i, _vp]),
     'rovit_joint_loss': (_i, [_vp] * 14 + [_i, _i, _f, _f, _f, _f, _vp]),
     'rovit_scale_buffers': (_i, [_vp, _vp, _i, _vp, _vp]),
-    'rovit_sq_norm_accum': (_i, [_vp, _sz, _vp, _vp]),
+    'rovit_sq_norm_accum': (_i, [_vp, _sz, _vp, _vp, _vp]),
     'rovit_mix_images': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp]),
     'rovit_clip_coef': (_i, [_vp, _f, _vp, _vp, _vp]),
     'rovit_adamw_flat': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _i, _vp]),

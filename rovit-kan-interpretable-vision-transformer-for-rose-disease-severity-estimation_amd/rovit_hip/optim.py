@@ -70,6 +70,7 @@ class RoViTAdamW(torch.optim.Optimizer):
         super().__init__([{'params': list(self.bb_params), 'lr': lr / 10.0}, {'params': list(self.other_params), 'lr': lr}],
                          dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._sq = torch.zeros((), dtype=torch.float32, device=dev)
+        self._sq_scratch = torch.zeros(520, dtype=torch.float32, device=dev)     # fixed-order block partials (bit-reproducible norm)
         self._coef = torch.ones((), dtype=torch.float32, device=dev)
         self._norm = torch.zeros((), dtype=torch.float32, device=dev)
         self.last_grad_norm: Optional[torch.Tensor] = None
@@ -119,10 +120,10 @@ class RoViTAdamW(torch.optim.Optimizer):
         if self.max_grad_norm is not None:
             self._sq.zero_()
             if bb:
-                call('rovit_sq_norm_accum', ptr(eng.grad_flat), eng.grad_flat.numel(), ptr(self._sq), sp)
+                call('rovit_sq_norm_accum', ptr(eng.grad_flat), eng.grad_flat.numel(), ptr(self._sq), ptr(self._sq_scratch), sp)
             for first, last in self._runs(active):      # padding floats of o_grad stay zero: sum whole aligned runs
                 call('rovit_sq_norm_accum', ptr(self.o_grad[first.offset:]),
-                     last.offset + (last.numel + 3) // 4 * 4 - first.offset, ptr(self._sq), sp)
+                     last.offset + (last.numel + 3) // 4 * 4 - first.offset, ptr(self._sq), ptr(self._sq_scratch), sp)
             call('rovit_clip_coef', ptr(self._sq), float(self.max_grad_norm), ptr(self._coef), ptr(self._norm), sp)
             self.last_grad_norm = self._norm
             coef = ptr(self._coef)

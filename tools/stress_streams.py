@@ -21,7 +21,7 @@ for B in (17, 32, 64, 256):
         for p in m.parameters(): p.grad = None
         f = m(x)
         (f * w).sum().backward()
-        g = torch.cat([p.grad.flatten() for n, p in m.named_parameters() if 'norm' not in n])
+        g = torch.cat([p.grad.flatten() for p in m.parameters()])
         if ref_f is None:
             ref_f, ref_i, ref_g = f.detach().clone(), fi, g.clone()
         else:

@@ -542,8 +542,10 @@ int launch_ws(const GemmArgs& g0, int epi, hipStream_t st) {
 //   * completion: a wave's vmcnt covers its own DMA pieces and its epilogue stores, in issue order.  Per tile the
 //     order is [DMA(t+2)] [stores(t)], so "tile t+1 landed" == at most SMAX + 6 younger ops outstanding.
 //   * the staged-output tile aliases the ring slot that was just consumed (same XOR idea against write conflicts).
-// Only for epilogues that issue no global LOADS inside the loop (BF16, GELU): a compiler-visible load would be
-// waited for with vmcnt(0) and drain the DMA queue.
+// Only for epilogues that issue no global LOADS inside the loop: a compiler-visible load would be waited for with
+// vmcnt(0) and drain the DMA queue.  BF16 and GELU need none; EPI_MUL (fc2 dgrad x gelu') brings its (64 x 192) tile
+// of the elementwise factor through a SECOND 3-slot ring by DMA as well (147 KB of LDS, one workgroup per CU, the
+// same 2 x 49 KB in flight per CU): 51.8 -> 39.3 us on the fc2-dgrad shape, 4.4 TB/s.
 // ------------------------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -553,6 +555,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_dma_kernel(const GemmArgs g, i
   constexpr int KS = 6, K = 192, BM = 64, TM = 4, NT = 256;
   constexpr int SLOT = BM * K;                              // bf16 elements per ring slot
   constexpr int SMAX = (EPI == EPI_GELU) ? 12 : 6;          // global stores one thread issues per tile
+  constexpr bool HAS_MASK = (EPI == EPI_MUL);               // second ring: the (64 x 192) tile of the elementwise factor
+  constexpr int PIECES = HAS_MASK ? 12 : 6;                 // DMA instructions one wave issues per tile
   extern __shared__ __attribute__((aligned(16))) bf16 lds[];   // ring[3][64][192]; ONE array (see cdna guide)
 
   const int nchunks = g.n_tiles;
@@ -588,6 +592,16 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_dma_kernel(const GemmArgs g, i
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(lds + slot * SLOT + (wave + 4 * i) * 512), 16, 0, 0);
     }
+    if (HAS_MASK) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        int gr = row0 + d_row[i];
+        gr = gr < g.M ? gr : g.M - 1;
+        const bf16* src = g.mul + (size_t)gr * g.ldm + n0 + d_col[i];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + (3 + slot) * SLOT + (wave + 4 * i) * 512), 16, 0, 0);
+      }
+    }
   };
   dma(tile0, 0);
   if (ntile > 1 && !(g.dbg & 4)) dma(tile0 + 1, 1);
@@ -620,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_dma_kernel(const GemmArgs g, i
     const int slot = t % 3;
     // tile t has landed once at most (DMA(t+1..) + this tile's predecessors' stores) are outstanding
     if (t + 2 < ntile) {
-      if (t == 0) wait_vmcnt<12>(); else wait_vmcnt<6 + SMAX>();
+      if (t == 0) wait_vmcnt<2 * PIECES>(); else wait_vmcnt<PIECES + SMAX>();
     } else {
       wait_vmcnt<0>();
     }
@@ -665,9 +679,16 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_dma_kernel(const GemmArgs g, i
         const int phys = (ch & ~7) | ((ch & 7) ^ (row & 7));
         const bf16x8 pv = *(const bf16x8*)(Cs + row * K + phys * 8);
         const size_t o = (size_t)m * g.ldo + n0 + ch * 8;
-        if (EPI == EPI_BF16 || (g.dbg & 8)) {
+        if (EPI == EPI_BF16 || (EPI == EPI_GELU && (g.dbg & 8))) {
           *(bf16x8*)(g.out + o) = pv;
-          if (EPI != EPI_BF16 && g.out2) *(bf16x8*)(g.out2 + o) = pv;
+          if (EPI == EPI_GELU && g.out2) *(bf16x8*)(g.out2 + o) = pv;
+        } else if (EPI == EPI_MUL) {
+          const int mphys = (ch & ~7) | ((ch & 7) ^ ((row >> 1) & 7));       // same swizzle the DMA wrote with
+          const bf16x8 mv = *(const bf16x8*)(lds + (3 + slot) * SLOT + row * K + mphys * 8);
+          bf16x8 rv2;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rv2[e] = (bf16)((float)pv[e] * (float)mv[e]);
+          *(bf16x8*)(g.out + o) = rv2;
         } else {
           bf16x8 av, dv;
 #pragma unroll
@@ -692,12 +713,12 @@ int launch_ws_dma(const GemmArgs& g0, hipStream_t st) {
   g.n_tiles = g.N / 192;
   constexpr int BM = 64;
   const int tiles_m = (g.M + BM - 1) / BM;
-  int pmax = 2 * g_cu_budget / g.n_tiles;
+  int pmax = (EPI == EPI_MUL ? 1 : 2) * g_cu_budget / g.n_tiles;      // workgroups per CU that fit the LDS ring(s)
   pmax = pmax < 8 ? 8 : pmax / 8 * 8;
   const int tpw = (tiles_m + pmax - 1) / pmax;
   int P = (tiles_m + tpw - 1) / tpw;
   P = (P + 7) / 8 * 8;
-  const size_t lds = (size_t)3 * BM * 192 * sizeof(bf16);
+  const size_t lds = (size_t)(EPI == EPI_MUL ? 6 : 3) * BM * 192 * sizeof(bf16);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_ws_dma_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1013,6 +1034,7 @@ extern "C" int rovit_gemm_nt(const void* A, int lda, const void* W, int ldw, int
   if (g_gemm_tile == 0 && N % 192 == 0) {
     if (K == 192 && epi == EPI_BF16) return launch_ws_dma<EPI_BF16>(g, (hipStream_t)stream);
     if (K == 192 && epi == EPI_GELU) return launch_ws_dma<EPI_GELU>(g, (hipStream_t)stream);
+    if (K == 192 && epi == EPI_MUL && !getenv("ROVIT_MUL_NO_DMA")) return launch_ws_dma<EPI_MUL>(g, (hipStream_t)stream);
     if (K == 192) return launch_ws<6, 1, 64>(g, epi, (hipStream_t)stream);
     if (K == 576) return launch_ws<9, 2, 32>(g, epi, (hipStream_t)stream);
     if (K == 768) return launch_ws<12, 2, 32>(g, epi, (hipStream_t)stream);

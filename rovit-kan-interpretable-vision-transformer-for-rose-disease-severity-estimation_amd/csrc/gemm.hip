@@ -729,6 +729,201 @@ int launch_ws_dma(const GemmArgs& g0, hipStream_t st) {
   return ROVIT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// K = 576 / 768, N = 192 GEMMs with a row-wise LayerNorm epilogue (fc2 forward + norm, fc1 / qkv dgrad + norm
+// backward), A tiles by LDS-DMA.  The register-staged kernel above splits K over wave pairs and needs an LDS
+// exchange buffer next to its double-buffered A tiles; here TWELVE waves each own 16 output columns over the whole
+// K (W fragments stationary: 96 / 72 registers), so there is no exchange and the 160 KB of LDS hold a 3-slot ring
+// of (32 x K) tiles.  The epilogue's own global loads (residual rows, xhat, rstd) are issued at the TOP of the
+// iteration so that their latency hides behind the MFMA phase (see the note at the loads about what the compiler's
+// wait for them costs).  Used for K = 576 (qkv dgrad + norm1 backward: step 6.37 -> 6.27 ms); the K = 768
+// instantiation spills at the 168-register budget of a 12-wave workgroup and stays off (ROVIT_KDMA768=1 enables it).
+// ------------------------------------------------------------------------------------------------------
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+template <int KT, int EPI>
+__global__ __launch_bounds__(768, 1) void gemm_kdma_kernel(const GemmArgs g, int tiles_per_wg, int n_tiles_m) {
+  constexpr int K = 32 * KT, BM = 32, NT = 768;
+  constexpr int CPRW = K / 8;                               // 16-byte chunks per row: 96 / 72
+  constexpr int SLOT = BM * K;
+  constexpr int PIECES = BM * CPRW / NT;                    // DMA instructions per wave and tile: 4 / 3
+  constexpr int NSTORE = (EPI == EPI_RESID_LN) ? 7 : 6;     // global stores a row-pass wave issues per tile
+  constexpr int CSTR = 192 + 8;
+  static_assert(BM * CPRW % NT == 0, "tile must split into whole DMA pieces");
+  extern __shared__ __attribute__((aligned(16))) bf16 lds[];   // ring[3][32][K]
+
+  const int p = blockIdx.x;
+  const int tile0 = p * tiles_per_wg;
+  int ntile = n_tiles_m - tile0;
+  ntile = ntile > tiles_per_wg ? tiles_per_wg : ntile;
+  if (ntile <= 0) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const bool row_wave = wave < 8;                           // waves 0..7 run the row pass (512 threads = 32 rows x 16 lanes)
+
+  auto dma = [&](int tile, int slot) {
+    const int row0 = tile * BM;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int c = 64 * (wave + 12 * i) + lane;            // linear 16-byte chunk of the slot
+      const int r = c / CPRW, x = c - r * CPRW;
+      int gr = row0 + r;
+      gr = gr < g.M ? gr : g.M - 1;
+      // physical chunk x of row r holds logical chunk x ^ (r & 7) (inside its group of 8): conflict-free fragment reads
+      const bf16* src = g.A + (size_t)gr * g.lda + ((x & ~7) | ((x & 7) ^ (r & 7))) * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(lds + slot * SLOT + (wave + 12 * i) * 512), 16, 0, 0);
+    }
+  };
+  dma(tile0, 0);
+  if (ntile > 1) dma(tile0 + 1, 1);
+  if (ntile > 2) dma(tile0 + 2, 2);
+
+  bf16x8 wf[KT];
+#pragma unroll
+  for (int ks = 0; ks < KT; ++ks) wf[ks] = *(const bf16x8*)(g.W + (size_t)(16 * wave + l15) * g.ldw + ks * 32 + lg * 8);
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias) {
+    const float4 bb = *(const float4*)(g.bias + 16 * wave + 4 * lg);
+    bias4 = (f32x4){bb.x, bb.y, bb.z, bb.w};
+  }
+  const int prow = tid >> 4, pc = tid & 15;                 // row pass: row of the tile, lane inside the row
+  wait_vmcnt<0>();                                          // prologue: W fragments (and the first tiles) are in
+
+  for (int t = 0; t < ntile; ++t) {
+    const int slot = t % 3;
+    if (t >= 1) {
+      if (t + 2 < ntile) { if (row_wave) wait_vmcnt<PIECES + NSTORE>(); else wait_vmcnt<PIECES>(); }
+      else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    // epilogue inputs of THIS tile first (their latency hides behind the MFMA phase).  NB the compiler waits for them
+    // with vmcnt(0) -- it does not order LDS-DMA against register loads -- so the DMA issued below is drained at the
+    // epilogue: effectively ONE tile ahead in flight, like the register-staged kernel, but without the exchange
+    // buffer and with the epilogue loads off the critical path.  (Hand-issued asm loads are not an option: the compiler
+    // may copy their destination registers before the data has landed.)
+    const int m = (tile0 + t) * BM + prow;
+    const bool live = row_wave && m < g.M;
+    const int mc = m < g.M ? m : g.M - 1;
+    f32x4 xo0, xo1, xo2;
+    u32x2_t hx0, hx1, hx2;
+    float rr = 0.f;
+    float* xrow = g.xres + (size_t)mc * g.ldx + 4 * pc;
+    if (row_wave) {
+      xo0 = *(const f32x4*)xrow; xo1 = *(const f32x4*)(xrow + 64); xo2 = *(const f32x4*)(xrow + 128);
+      if (EPI == EPI_LNBWD) {
+        const bf16* hrow = g.mul + (size_t)mc * g.ldm + 4 * pc;
+        hx0 = *(const u32x2_t*)hrow; hx1 = *(const u32x2_t*)(hrow + 64); hx2 = *(const u32x2_t*)(hrow + 128);
+        rr = g.pos[mc];
+      }
+    }
+    const bool dma_now = t >= 1 && t + 2 < ntile;
+    if (dma_now) dma(tile0 + t + 2, (t + 2) % 3);
+
+    f32x4 acc[2] = {bias4, bias4};
+    const bf16* Ac = lds + slot * SLOT;
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) {
+      const int lc = ks * 4 + lg;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = i * 16 + l15;
+        const bf16x8 af = *(const bf16x8*)(Ac + row * K + ((lc & ~7) | ((lc & 7) ^ (row & 7))) * 8);
+        acc[i] = mfma16(wf[ks], af, acc[i]);               // D[n][m]
+      }
+    }
+    barrier_lds();                                          // every wave is done with the slot: reuse it for C
+    bf16* Cs = lds + slot * SLOT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *(bf16x4*)(Cs + (i * 16 + l15) * CSTR + 16 * wave + 4 * lg) = pack4(acc[i]);
+    barrier_lds();
+    if (row_wave) {
+      float v[12];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const bf16x4 tv = *(const bf16x4*)(Cs + prow * CSTR + 64 * i + 4 * pc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * i + e] = (float)tv[e];
+      }
+      f32x4 xs[3] = {xo0, xo1, xo2};
+      f32x4* xp = (f32x4*)(g.xres + (size_t)mc * g.ldx);
+      if (EPI == EPI_RESID_LN) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { xs[i][e] += v[4 * i + e]; v[4 * i + e] = xs[i][e]; }
+          sum += (xs[i][0] + xs[i][1]) + (xs[i][2] + xs[i][3]);
+        }
+        const float mean = wave_sum16(sum) * (1.f / 192.f);
+        float qs = 0.f;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) { v[e] -= mean; qs += v[e] * v[e]; }
+        const float r = rsqrtf(wave_sum16(qs) * (1.f / 192.f) + g.eps);
+        if (live) {
+          bf16x4* hp = (bf16x4*)(g.out + (size_t)m * g.ldo);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) xp[16 * i + pc] = xs[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            f32x4 tq = {v[4 * i] * r, v[4 * i + 1] * r, v[4 * i + 2] * r, v[4 * i + 3] * r};
+            hp[16 * i + pc] = pack4(tq);
+          }
+          if (pc == 0) g.rstd_out[m] = r;
+        }
+      } else {
+        const u32x2_t hxs[3] = {hx0, hx1, hx2};
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const bf16x4 hb = __builtin_bit_cast(bf16x4, hxs[i]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { s1 += v[4 * i + e]; s2 += v[4 * i + e] * (float)hb[e]; }
+        }
+        const float c1 = wave_sum16(s1) * (1.f / 192.f), c2 = wave_sum16(s2) * (1.f / 192.f);
+        if (live) {
+          bf16x4* bp = (bf16x4*)(g.out + (size_t)m * g.ldo);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const bf16x4 hb = __builtin_bit_cast(bf16x4, hxs[i]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xs[i][e] += rr * (v[4 * i + e] - c1 - (float)hb[e] * c2);
+          }
+#pragma unroll
+          for (int i = 0; i < 3; ++i) xp[16 * i + pc] = xs[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) bp[16 * i + pc] = pack4(xs[i]);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the next top barrier retires this tile's LDS reads
+  }
+}
+
+template <int KT, int EPI>
+int launch_kdma(const GemmArgs& g0, hipStream_t st) {
+  GemmArgs g = g0;
+  constexpr int BM = 32;
+  const int tiles_m = (g.M + BM - 1) / BM;
+  int pmax = g_cu_budget;                                   // one 12-wave workgroup per CU
+  const int tpw = (tiles_m + pmax - 1) / pmax;
+  const int P = (tiles_m + tpw - 1) / tpw;
+  const size_t lds = (size_t)3 * BM * 32 * KT * sizeof(bf16);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_kdma_kernel<KT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_kdma_kernel<KT, EPI>), dim3(P), dim3(768), lds, st, g, tpw, tiles_m);
+  ROVIT_CHECK_LAUNCH("gemm_kdma_kernel");
+  return ROVIT_OK;
+}
+// the K = 768 instantiation needs 96 registers of stationary W per lane and spills at the 168-register budget of a
+// 12-wave workgroup: off unless ROVIT_KDMA768=1
+static bool kdma_k768() { static const bool on = getenv("ROVIT_KDMA768") && getenv("ROVIT_KDMA768")[0] == '1'; return on; }
+static bool kdma_enabled() { static const bool on = !(getenv("ROVIT_KDMA") && getenv("ROVIT_KDMA")[0] == '0'); return on; }
+
 template <int BM, int BN, int WM, int WN>
 int launch_nt(const GemmArgs& g0, int epi, hipStream_t st) {
   GemmArgs g = g0;
@@ -1140,6 +1335,7 @@ extern "C" int rovit_gemm_resid_ln(const void* A, int lda, const void* W, int ld
   g.A = (const bf16*)A; g.lda = lda; g.W = (const bf16*)W; g.ldw = ldw; g.M = M; g.N = 192; g.K = K; g.bias = bias;
   g.xres = X; g.ldx = 192; g.out = (bf16*)xhat_out; g.ldo = 192; g.rstd_out = rstd_out; g.eps = eps; g.dbg = g_gemm_dbg;
   if (K == 192) return launch_ws<6, 1, 64>(g, EPI_RESID_LN, (hipStream_t)stream);
+  if (kdma_enabled() && xhat_out && (K == 576 || kdma_k768())) return K == 576 ? launch_kdma<18, EPI_RESID_LN>(g, (hipStream_t)stream) : launch_kdma<24, EPI_RESID_LN>(g, (hipStream_t)stream);
   if (K == 576) return launch_ws<9, 2, 32>(g, EPI_RESID_LN, (hipStream_t)stream);
   return launch_ws<12, 2, 32>(g, EPI_RESID_LN, (hipStream_t)stream);
 }
@@ -1156,6 +1352,7 @@ extern "C" int rovit_gemm_ln_bwd(const void* dY, int ldy, const void* W, int ldw
   g.A = (const bf16*)dY; g.lda = ldy; g.W = (const bf16*)W; g.ldw = ldw; g.M = M; g.N = 192; g.K = K;
   g.mul = (const bf16*)xhat; g.ldm = 192; g.pos = rstd; g.xres = dX; g.ldx = 192; g.out = (bf16*)dXb; g.ldo = 192; g.dbg = g_gemm_dbg;
   if (K == 192) return launch_ws<6, 1, 64>(g, EPI_LNBWD, (hipStream_t)stream);
+  if (kdma_enabled() && (K == 576 || kdma_k768())) return K == 576 ? launch_kdma<18, EPI_LNBWD>(g, (hipStream_t)stream) : launch_kdma<24, EPI_LNBWD>(g, (hipStream_t)stream);
   if (K == 576) return launch_ws<9, 2, 32>(g, EPI_LNBWD, (hipStream_t)stream);
   return launch_ws<12, 2, 32>(g, EPI_LNBWD, (hipStream_t)stream);
 }

@@ -390,7 +390,9 @@ def test_gemm_resid_ln_fused(M, K):
     X2 = X0.clone()                                                   # no LayerNorm requested: plain residual add
     native.call('rovit_gemm_resid_ln', native.ptr(A), K, native.ptr(W), K, M, K, native.ptr(bias), native.ptr(X2), None, None, 1e-6,
                 native.stream_ptr())
-    assert torch.equal(X2, X)
+    # (for K = 576 the two calls run different kernels -- K split over wave pairs vs. one wave over the whole K -- so the
+    # fp32 summation order differs and a branch output may round to the neighbouring bf16)
+    assert float((X2 - X).abs().max()) < 2e-2 and float((X2 - X).abs().mean()) < 1e-4
 
 
 @pytest.mark.parametrize('M,K', [(394, 768), (1000, 576), (50, 192)])

@@ -810,14 +810,16 @@ __global__ __launch_bounds__(768, 1) void gemm_kdma_kernel(const GemmArgs g, int
     u32x2_t hx0, hx1, hx2;
     float rr = 0.f;
     float* xrow = g.xres + (size_t)mc * g.ldx + 4 * pc;
-    if (row_wave) {
+    constexpr bool PREFETCH = KT <= 18;                     // K = 768: 96 registers of W leave no room to hold them over the MFMAs
+    auto load_inputs = [&]() {
       xo0 = *(const f32x4*)xrow; xo1 = *(const f32x4*)(xrow + 64); xo2 = *(const f32x4*)(xrow + 128);
       if (EPI == EPI_LNBWD) {
         const bf16* hrow = g.mul + (size_t)mc * g.ldm + 4 * pc;
         hx0 = *(const u32x2_t*)hrow; hx1 = *(const u32x2_t*)(hrow + 64); hx2 = *(const u32x2_t*)(hrow + 128);
         rr = g.pos[mc];
       }
-    }
+    };
+    if (PREFETCH && row_wave) load_inputs();
     const bool dma_now = t >= 1 && t + 2 < ntile;
     if (dma_now) dma(tile0 + t + 2, (t + 2) % 3);
 
@@ -839,6 +841,7 @@ __global__ __launch_bounds__(768, 1) void gemm_kdma_kernel(const GemmArgs g, int
     for (int i = 0; i < 2; ++i) *(bf16x4*)(Cs + (i * 16 + l15) * CSTR + 16 * wave + 4 * lg) = pack4(acc[i]);
     barrier_lds();
     if (row_wave) {
+      if (!PREFETCH) load_inputs();
       float v[12];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {

@@ -762,16 +762,25 @@ __global__ __launch_bounds__(768, 1) void gemm_kdma_kernel(const GemmArgs g, int
   const int l15 = lane & 15, lg = lane >> 4;
   const bool row_wave = wave < 8;                           // waves 0..7 run the row pass (512 threads = 32 rows x 16 lanes)
 
+  // per piece: (row << 16) | swizzled source column, one register each; the source address is rebuilt per tile from
+  // 32-bit offsets (keeping 64-bit per-lane pointers alive across the loop is what spills at K = 768)
+  unsigned pk[PIECES];
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) {
+    const int c = 64 * (wave + 12 * i) + lane;              // linear 16-byte chunk of the slot
+    const int r = c / CPRW, x = c - r * CPRW;
+    // physical chunk x of row r holds logical chunk x ^ (r & 7) (inside its group of 8): conflict-free fragment reads
+    pk[i] = ((unsigned)r << 16) | (unsigned)(((x & ~7) | ((x & 7) ^ (r & 7))) * 8);
+  }
   auto dma = [&](int tile, int slot) {
     const int row0 = tile * BM;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-      const int c = 64 * (wave + 12 * i) + lane;            // linear 16-byte chunk of the slot
-      const int r = c / CPRW, x = c - r * CPRW;
-      int gr = row0 + r;
+      unsigned q = pk[i];
+      asm volatile("" : "+v"(q));                           // keep the address arithmetic inside the loop
+      int gr = row0 + (int)(q >> 16);
       gr = gr < g.M ? gr : g.M - 1;
-      // physical chunk x of row r holds logical chunk x ^ (r & 7) (inside its group of 8): conflict-free fragment reads
-      const bf16* src = g.A + (size_t)gr * g.lda + ((x & ~7) | ((x & 7) ^ (r & 7))) * 8;
+      const bf16* src = g.A + ((unsigned)gr * (unsigned)g.lda + (q & 0xffffu));
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(lds + slot * SLOT + (wave + 12 * i) * 512), 16, 0, 0);
     }
@@ -809,12 +818,15 @@ __global__ __launch_bounds__(768, 1) void gemm_kdma_kernel(const GemmArgs g, int
     f32x4 xo0, xo1, xo2;
     u32x2_t hx0, hx1, hx2;
     float rr = 0.f;
-    float* xrow = g.xres + (size_t)mc * g.ldx + 4 * pc;
+    // 32-bit element offsets from the (uniform) base pointers: saddr + voffset addressing, no 64-bit pointers held in
+    // VGPRs across the loop (at K = 768 those were what spilled)
+    const unsigned xoff = (unsigned)mc * (unsigned)g.ldx + 4u * pc;
+    float* xrow = g.xres + xoff;
     constexpr bool PREFETCH = KT <= 18;                     // K = 768: 96 registers of W leave no room to hold them over the MFMAs
     auto load_inputs = [&]() {
       xo0 = *(const f32x4*)xrow; xo1 = *(const f32x4*)(xrow + 64); xo2 = *(const f32x4*)(xrow + 128);
       if (EPI == EPI_LNBWD) {
-        const bf16* hrow = g.mul + (size_t)mc * g.ldm + 4 * pc;
+        const bf16* hrow = g.mul + ((unsigned)mc * (unsigned)g.ldm + 4u * pc);
         hx0 = *(const u32x2_t*)hrow; hx1 = *(const u32x2_t*)(hrow + 64); hx2 = *(const u32x2_t*)(hrow + 128);
         rr = g.pos[mc];
       }
@@ -850,27 +862,29 @@ __global__ __launch_bounds__(768, 1) void gemm_kdma_kernel(const GemmArgs g, int
         for (int e = 0; e < 4; ++e) v[4 * i + e] = (float)tv[e];
       }
       f32x4 xs[3] = {xo0, xo1, xo2};
-      f32x4* xp = (f32x4*)(g.xres + (size_t)mc * g.ldx);
+      f32x4* xp = (f32x4*)(g.xres + (unsigned)mc * (unsigned)g.ldx);
       if (EPI == EPI_RESID_LN) {
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { xs[i][e] += v[4 * i + e]; v[4 * i + e] = xs[i][e]; }
+          for (int e = 0; e < 4; ++e) xs[i][e] += v[4 * i + e];
           sum += (xs[i][0] + xs[i][1]) + (xs[i][2] + xs[i][3]);
         }
         const float mean = wave_sum16(sum) * (1.f / 192.f);
         float qs = 0.f;
 #pragma unroll
-        for (int e = 0; e < 12; ++e) { v[e] -= mean; qs += v[e] * v[e]; }
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = xs[i][e] - mean; qs += d * d; }
         const float r = rsqrtf(wave_sum16(qs) * (1.f / 192.f) + g.eps);
         if (live) {
-          bf16x4* hp = (bf16x4*)(g.out + (size_t)m * g.ldo);
+          bf16x4* hp = (bf16x4*)(g.out + (unsigned)m * (unsigned)g.ldo);
 #pragma unroll
           for (int i = 0; i < 3; ++i) xp[16 * i + pc] = xs[i];
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            f32x4 tq = {v[4 * i] * r, v[4 * i + 1] * r, v[4 * i + 2] * r, v[4 * i + 3] * r};
+            f32x4 tq = {(xs[i][0] - mean) * r, (xs[i][1] - mean) * r, (xs[i][2] - mean) * r, (xs[i][3] - mean) * r};
             hp[16 * i + pc] = pack4(tq);
           }
           if (pc == 0) g.rstd_out[m] = r;
@@ -886,7 +900,7 @@ __global__ __launch_bounds__(768, 1) void gemm_kdma_kernel(const GemmArgs g, int
         }
         const float c1 = wave_sum16(s1) * (1.f / 192.f), c2 = wave_sum16(s2) * (1.f / 192.f);
         if (live) {
-          bf16x4* bp = (bf16x4*)(g.out + (size_t)m * g.ldo);
+          bf16x4* bp = (bf16x4*)(g.out + (unsigned)m * (unsigned)g.ldo);
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             const bf16x4 hb = __builtin_bit_cast(bf16x4, hxs[i]);

@@ -3,6 +3,17 @@
 //   gemm_nt   C[M,N] = A[M,K] * W[N,K]^T  (+ fused epilogue)       forward linears and dgrads
 //   wgrad     G[N,K] = dY[M,N]^T * A[M,K], colsum(dY)               weight gradients (split over M, slabs)
 //
+// Kernels, in the order they appear (all persistent and weight-stationary except the first):
+//   gemm_nt_kernel      128x192 / 128x96 tiles, operands through LDS: generic fallback (rovit_set_gemm_tile)
+//   gemm_ws_kernel      W fragments in registers, A tiles register-staged into a double-buffered LDS tile;
+//                       K = 768 splits K over wave pairs.  Used for the row-wise LayerNorm epilogues at K = 192 / 768
+//                       and the patch embedding
+//   gemm_ws_dma_kernel  K = 192: A tiles by LDS-DMA into a 3-slot ring (qkv fwd, fc1 fwd + GELU, proj dgrad) and, with
+//                       a second ring for the elementwise factor, fc2 dgrad x gelu'
+//   gemm_kdma_kernel    K = 576: 12 waves x 16 columns over the whole K, LDS-DMA ring, row-wise epilogue
+//                       (qkv dgrad + LayerNorm backward)
+//   wgrad_kernel, wgrad_reduce_batch_kernel, wgrad_affine_batch_kernel, wgrad_affine_finalize_kernel
+//
 // Reference arithmetic being restated: timm VisionTransformer's Linear layers (qkv/proj/fc1/fc2, patch-embed
 // conv as an im2col GEMM) reached through /root/reference/models/backbone.py:12-25, and their autograd
 // backward (training/trainer.py:119,136).

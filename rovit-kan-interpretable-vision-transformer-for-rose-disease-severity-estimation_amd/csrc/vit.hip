@@ -1,7 +1,7 @@
 // DeiT-Tiny backbone forward / backward: the launch sequence over the kernels in gemm.hip, attention.hip and
-// elementwise.hip.  Work is ordered on the caller's stream; batches >= 16 additionally use ONE library-owned side
-// stream (forked from and joined back into the caller's stream inside each call: half-batch chains in the forward,
-// weight gradients in the backward).  Nothing here allocates device memory or synchronises with the host.
+// elementwise.hip.  Work is ordered on the caller's stream; ONE library-owned side stream is forked from and joined back into
+// it inside each call (the second half-batch chain in the forward of batches >= 16, the weight gradients in the
+// backward).  Nothing here allocates device memory or synchronises with the host.
 //
 // Reference being restated: DeiTTinyBackbone.forward (/root/reference/models/backbone.py:23-25) ->
 // timm VisionTransformer.forward, and its autograd backward (training/trainer.py:119,136).

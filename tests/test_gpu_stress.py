@@ -127,3 +127,53 @@ def test_training_trajectory_is_bit_reproducible():
     for (n, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
         assert torch.equal(p, q), n
     assert float(la[-1]) < float(la[0])
+
+
+@pytest.mark.parametrize('K', [576, 768])
+def test_fused_dgrad_layernorm_backward_gemm_is_reproducible_at_full_size(K):
+    """The dgrad + LayerNorm-backward GEMM (K=576: LDS-DMA ring, 12 waves; K=768: register-staged) at M = 50432."""
+    from rovit_hip import native
+    from rovit_hip.native import call, ptr
+    M, D = 256 * 197, 192
+    torch.manual_seed(1)
+    dy = torch.randn(M, K, device=dev()).to(torch.bfloat16)
+    w = (torch.randn(D, K, device=dev()) * 0.05).to(torch.bfloat16)
+    xh = torch.randn(M, D, device=dev()).to(torch.bfloat16)
+    rstd = torch.rand(M, device=dev()) + 0.5
+    x0 = torch.randn(M, D, device=dev())
+    ref = None
+    for rep in range(60):
+        dx = x0.clone()
+        dxb = torch.full((M, D), 7.0, device=dev(), dtype=torch.bfloat16)
+        call('rovit_gemm_ln_bwd', ptr(dy), K, ptr(w), K, M, K, ptr(xh), ptr(rstd), ptr(dx), ptr(dxb), native.stream_ptr())
+        if ref is None:
+            ref = (dx, dxb)
+            g = dy.float() @ w.float().t()                                   # dxhat
+            h = xh.float()
+            want = x0 + rstd[:, None] * (g - g.mean(1, keepdim=True) - h * (g * h).mean(1, keepdim=True))
+            assert float((dx - want).abs().max()) < 5e-2                     # bf16 rounding of dxhat (|dxhat| ~ 1.4)
+            assert torch.equal(dxb, dx.to(torch.bfloat16))
+            continue
+        assert torch.equal(dx, ref[0]) and torch.equal(dxb, ref[1]), rep
+
+
+def test_masked_dgrad_gemm_is_reproducible_at_full_size():
+    """fc2 dgrad x gelu' (LDS-DMA ring for the A tiles and a second one for the elementwise factor) at M = 50432."""
+    from rovit_hip import native
+    from rovit_hip.native import call, ptr
+    M, N, K = 256 * 197, 768, 192
+    torch.manual_seed(2)
+    a = torch.randn(M, K, device=dev()).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev()) * 0.05).to(torch.bfloat16)
+    mask = torch.rand(M, N, device=dev()).to(torch.bfloat16)
+    ref = None
+    for rep in range(60):
+        out = torch.full((M, N), 7.0, device=dev(), dtype=torch.bfloat16)
+        call('rovit_gemm_nt', ptr(a), K, ptr(w), K, M, N, K, None, 3, ptr(out), N, None, None, 0, ptr(mask), N, None, 0,
+             native.stream_ptr())
+        if ref is None:
+            ref = out
+            want = ((a[:4096].float() @ w.float().t()).to(torch.bfloat16).float() * mask[:4096].float())
+            assert float((out[:4096].float() - want).abs().max()) < 2e-2
+            continue
+        assert torch.equal(out, ref), rep

@@ -490,3 +490,46 @@ def test_attention_probability_taps_vs_oracle():
         assert p.shape == (B, 3, 197, 197) and p.dtype == torch.float32
         assert float((p.sum(-1) - 1).abs().max()) < 1e-5
         assert float((p.cpu() - r).abs().max()) < 5e-3, i
+
+
+def test_frozen_backbone_training_step_and_checkpoint_round_trip():
+    """Curriculum epochs 1-5 of the reference train with the backbone frozen (trainer.py:63,245): the backbone's backward
+    is skipped entirely (no gradients, parameters untouched), heads still train; after unfreeze_backbone() everything
+    moves.  state_dict() keys are the reference's and a save/load round trip reproduces the outputs bit for bit, with
+    the parameters living as views of the optimizer's flat buffers."""
+    import io
+    from models.rovit_kan import RoViTKAN
+    from rovit_hip.optim import RoViTAdamW
+    from rovit_hip.losses import JointLoss
+    torch.manual_seed(17)
+    m = RoViTKAN(pretrained=False, dropout=0.0).to(dev()).train()
+    opt = RoViTAdamW(m, lr=1e-3)
+    lf = JointLoss()
+    x = torch.randn(6, 3, 224, 224, device=dev())
+    y = torch.randint(0, 4, (6,), device=dev())
+    m.freeze_backbone()
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    opt.zero_grad()
+    lf(m(x), y, y, 4)['total_loss'].backward()
+    assert all(p.grad is None for n, p in m.named_parameters() if n.startswith('backbone.'))
+    opt.step()
+    for n, p in m.named_parameters():
+        assert torch.equal(p, before[n]) == n.startswith('backbone.'), n
+    m.unfreeze_backbone()
+    opt.zero_grad()
+    lf(m(x), y, y, 4)['total_loss'].backward()
+    opt.step()
+    assert not torch.equal(m.backbone.model.blocks[0].attn.qkv.weight, before['backbone.model.blocks.0.attn.qkv.weight'])
+    # checkpoint round trip
+    sd = m.state_dict()
+    assert 'backbone.model.blocks.11.mlp.fc2.weight' in sd and 'kan_module.kan_layers.0.knots' in sd
+    buf = io.BytesIO()
+    torch.save(sd, buf)
+    buf.seek(0)
+    m2 = RoViTKAN(pretrained=False, dropout=0.0).to(dev())
+    m2.load_state_dict(torch.load(buf, weights_only=True))
+    m.eval(); m2.eval()
+    with torch.no_grad():
+        o1, o2 = m(x), m2(x)
+    for k in ('cls_logits', 'features', 'ordinal_logits', 'mu', 'log_var', 'kan_severity'):
+        assert torch.equal(o1[k], o2[k]), k

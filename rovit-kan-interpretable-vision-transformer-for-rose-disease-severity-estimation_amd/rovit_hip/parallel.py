@@ -4,8 +4,8 @@ The reference is single-process (no collectives anywhere), 
 independent (LayerNorm only), every rank holds a full replica, and the only exchange is one averaged all-reduce of
 the gradients per step.  The backbone's gradients live in ONE flat fp32 buffer (VitEngine.grad_flat) written by the
 HIP backward block range by block range; each finished range is all-reduced on a side stream while the next range's
-kernels run (bucketed overlap, 3-4 buckets of ~5-7 MB: large enough for xGMI's per-link bandwidth, small enough
-that the last bucket's exposed tail is short).  Head/KAN gradients (0.7 MB) go in one flat bucket after backward.
+kernels run (bucketed overlap, 3 buckets tapering 6 : 4 : 2 blocks = 10.6 / 7.1 / 4.1 MB: large enough for xGMI's
+per-link bandwidth, and the last bucket, whose all-reduce is exposed, is the smallest).  Head/KAN gradients (0.7 MB) go in one flat bucket after backward.
 
 The class only needs ``flat`` tensors and ranges, so its bucket logic is exercised on CPU with the gloo backend.
 """
@@ -17,10 +17,21 @@ import torch
 import torch.distributed as dist
 
 
-def block_ranges(depth: int, buckets: int) -> List[Tuple[int, int]]:
-    """Split blocks depth-1..0 into `buckets` contiguous ranges in backward order, e.g. 12,3 -> (11,8),(7,4),(3,0)."""
+def block_ranges(depth: int, buckets: int, taper: bool = False) -> List[Tuple[int, int]]:
+    """Split blocks depth-1..0 into `buckets` contiguous ranges in backward order, e.g. 12,3 -> (11,8),(7,4),(3,0).
+    taper=True makes the ranges shrink (weights buckets : ... : 2 : 1, e.g. 12,3 -> (11,6),(5,2),(1,0)): the early,
+    large buckets have the rest of the backward to hide behind, the last one -- whose all-reduce is exposed -- is small."""
     buckets = max(1, min(buckets, depth))
-    edges = [round(i * depth / buckets) for i in range(buckets + 1)]
+    if taper and buckets > 1:
+        total = buckets * (buckets + 1) // 2
+        cum, edges = 0, [0]
+        for i in range(buckets):
+            cum += buckets - i
+            edges.append(round(cum * depth / total))
+        for i in range(1, buckets + 1):                      # every bucket keeps at least one block
+            edges[i] = min(max(edges[i], edges[i - 1] + 1), depth - (buckets - i))
+    else:
+        edges = [round(i * depth / buckets) for i in range(buckets + 1)]
     return [(depth - 1 - edges[i], depth - edges[i + 1]) for i in range(buckets)]
 
 
@@ -91,7 +102,7 @@ class GradSync:
         self.reducer = FlatBucketAllReduce(group, force=force)
         self.world = self.reducer.world
         self.active = self.world > 1 or self.reducer.force
-        self.ranges = block_ranges(self.depth, buckets)
+        self.ranges = block_ranges(self.depth, buckets, taper=True)
         params = model.backbone.model.ordered_parameters()
         sizes = [p.numel() for p in params]
         self.prefix = sum(sizes[:6])

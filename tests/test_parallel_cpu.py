@@ -35,7 +35,7 @@ def _worker(rank, world, port, q):
         model = RoViTKAN(pretrained=False)
         sync = GradSync(model, buckets=3)
         eng = model.backbone.model.engine
-        assert eng.backward_ranges == [(11, 8), (7, 4), (3, 0)] == block_ranges(12, 3)
+        assert eng.backward_ranges == [(11, 6), (5, 2), (1, 0)] == block_ranges(12, 3, taper=True)
         params = model.backbone.model.ordered_parameters()
         eng.ensure_grads(params)
         total = eng.grad_flat.numel()
@@ -60,7 +60,7 @@ def _worker(rank, world, port, q):
         # last range also carries cls/pos/patch/final-norm (the first 6 tensors of the flat buffer)
         prefix = sum(p.numel() for p in params[:6])
         last_bucket = [c for c in issued[:3] if c[0] == 0][0]
-        q.put((rank, bool(ok), bool(contiguous), last_bucket[1] == prefix + 4 * sync.block_numel, len(sync.reducer.issued)))
+        q.put((rank, bool(ok), bool(contiguous), last_bucket[1] == prefix + 2 * sync.block_numel, len(sync.reducer.issued)))
     finally:
         dist.destroy_process_group()
 
@@ -88,6 +88,9 @@ def test_block_ranges():
     assert block_ranges(12, 1) == [(11, 0)]
     assert block_ranges(12, 4) == [(11, 9), (8, 6), (5, 3), (2, 0)]
     assert block_ranges(2, 5) == [(1, 1), (0, 0)]
+    assert block_ranges(12, 3, taper=True) == [(11, 6), (5, 2), (1, 0)]
+    assert block_ranges(12, 4, taper=True) == [(11, 7), (6, 4), (3, 1), (0, 0)]
+    assert block_ranges(3, 3, taper=True) == [(2, 2), (1, 1), (0, 0)]
     for d in (1, 2, 5, 12):
         for b in (1, 2, 3, 4, 7):
             r = block_ranges(d, b)

@@ -193,6 +193,7 @@ class VitEngine:
         self.backward_ranges: Optional[Sequence] = None
         self.range_hook = None
         self.notify_stream: Optional[torch.cuda.Stream] = None
+        self.pre_backward_hook = None    # called as hook(engine) when the backbone's backward starts (head/KAN grads are final)
 
     # -- prepared weights ---------------------------------------------------------------------
     def prepare(self, params: Sequence[torch.Tensor]):
@@ -281,6 +282,8 @@ class VitFn(torch.autograd.Function):
         depth = engine.depth
         ranges = engine.backward_ranges or [(depth - 1, 0)]
         hooked = engine.range_hook is not None and fresh
+        if hooked and engine.pre_backward_hook is not None:
+            engine.pre_backward_hook(engine)
         for first, last in ranges:
             if hooked and engine.notify_stream is not None and last > 0:
                 # the range's gradients become visible on the reduction stream; this stream is not stalled

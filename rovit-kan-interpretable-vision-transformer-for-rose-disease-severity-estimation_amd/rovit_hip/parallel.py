@@ -111,6 +111,7 @@ class GradSync:
         if self.active:
             self.engine.backward_ranges = self.ranges
             self.engine.range_hook = self._on_range
+            self.engine.pre_backward_hook = self._on_backbone_backward_start
             dev = params[0].device
             if dev.type == 'cuda':
                 self.engine.notify_stream = self.reducer.stream_for(dev)
@@ -126,15 +127,42 @@ class GradSync:
         off, n = self.slice_for(first, last)
         self.reducer.reduce_slice(engine.grad_flat, off, n, ordered)
 
+    def _reduce_others(self):
+        """One flat bucket for the head/KAN gradients; returns (flat, grads) or None."""
+        grads = [p.grad for p in self.other_params if p.grad is not None]
+        if not grads:
+            return None
+        flat = torch._utils._flatten_dense_tensors(grads)            # one cat kernel
+        self.reducer.reduce_slice(flat, 0, flat.numel())
+        return flat, grads
+
+    def _on_backbone_backward_start(self, engine):
+        # Autograd runs the heads' and the KAN's backward (and their AccumulateGrad nodes, which have top priority)
+        # before the backbone's: their gradients are final here, so their all-reduce hides behind the whole backbone
+        # backward instead of being exposed after it.
+        self._early = self._reduce_others()
+
     def finish(self):
-        """Call after loss.backward(): reduce the small head/KAN gradients, then join the side stream."""
+        """Call after loss.backward(): the small head/KAN bucket (already in flight if the backbone ran a backward,
+        else reduced now), then join the reduction stream."""
         if not self.active:
             return
-        grads = [p.grad for p in self.other_params if p.grad is not None]
-        if grads:
-            flat = torch._utils._flatten_dense_tensors(grads)            # one cat kernel
-            self.reducer.reduce_slice(flat, 0, flat.numel())
-            self.reducer.finish(flat.device)
-            torch._foreach_copy_(grads, torch._utils._unflatten_dense_tensors(flat, grads))   # one multi-tensor copy
+        pending = getattr(self, '_early', None)
+        self._early = None
+        late = None
+        if pending is None:
+            pending = self._reduce_others()
+        else:
+            # anything that received its gradient only after the early bucket went out (not expected: AccumulateGrad
+            # nodes run as soon as their gradient is ready) still gets reduced
+            seen = {id(g) for g in pending[1]}
+            rest = [p.grad for p in self.other_params if p.grad is not None and id(p.grad) not in seen]
+            if rest:
+                late = (torch._utils._flatten_dense_tensors(rest), rest)
+                self.reducer.reduce_slice(late[0], 0, late[0].numel())
+        if pending is not None:
+            self.reducer.finish(pending[0].device)
+            for flat, grads in ((pending,) if late is None else (pending, late)):
+                torch._foreach_copy_(grads, torch._utils._unflatten_dense_tensors(flat, grads))   # one multi-tensor copy
         else:
             self.reducer.finish()

@@ -351,8 +351,12 @@ def test_bucketed_grad_sync_one_rank_matches_plain_backward():
     from models.rovit_kan import RoViTKAN
     from rovit_hip.losses import JointLoss
     from rovit_hip.parallel import GradSync
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29533')
+    import socket
+    with socket.socket() as sk:                                  # a free rendezvous port on the loopback interface
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
     torch.manual_seed(3)
     m = RoViTKAN(pretrained=False).to(dev()).eval()
     x = torch.randn(20, 3, 224, 224, device=dev())

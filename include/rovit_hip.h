@@ -104,6 +104,17 @@ int rovit_vit_forward_taps(const float* images, const float* const* params, cons
                            void* const* attn_taps, float* const* prob_taps, int batch, int depth, rovit_stream_t stream);
 int rovit_vit_backward(const float* d_features, const float* const* params, const void* prep, void* workspace,
                        float* const* grads, int batch, int depth, int first_block, int last_block, rovit_stream_t stream);
+/* Where a saved activation / backward temporary of block `block` lives inside a TRAINING workspace
+ * (rovit_vit_workspace_bytes(batch, depth, 1)): byte offset in *offset, extent in *bytes.  This is what the
+ * explainability taps read (reference explainability/gradcam.py:18-60 hooks blocks[-1].norm1 for activations and
+ * gradients; attention_maps.py:24-32 hooks blocks[i].attn): the fused kernels' own buffers, no extra copy.
+ *   XHAT1 / XHAT2: bf16 (M,192) normalised rows before the norm1 / norm2 affine; RSTD1 / RSTD2: fp32 (M)
+ *   QKV: bf16 (M,576); ATTN_O: bf16 (M,192) attention output before proj; ACT: bf16 (M,768) gelu(fc1)
+ *   DQKV: bf16 (M,576) gradient w.r.t. the qkv output of `block`, valid after rovit_vit_backward has processed that
+ *   block and before it processes block-2 (call it with first_block = last_block = block, then read) */
+enum { ROVIT_WS_XHAT1 = 0, ROVIT_WS_RSTD1 = 1, ROVIT_WS_QKV = 2, ROVIT_WS_ATTN_O = 3, ROVIT_WS_XHAT2 = 4, ROVIT_WS_RSTD2 = 5,
+       ROVIT_WS_ACT = 6, ROVIT_WS_DQKV = 7 };
+int rovit_vit_workspace_field(int batch, int depth, int field, int block, size_t* offset, size_t* bytes);
 /* rovit_vit_backward for a data-parallel caller: for last_block > 0 the call does not wait for the range's weight
  * gradients on `stream`; `notify_stream` (the caller's reduction stream) is made to wait for them instead.  Issue the
  * ranges in order down to last_block == 0; that call joins everything into `stream`. */
@@ -187,12 +198,14 @@ int rovit_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, con
 /* ------------------------------------------------------------------------------------------------------------
  * Joint multi-task loss, forward + gradient in one launch: JointLoss.forward (training/losses.py:139-181) with
  * FocalLoss (:15-38), OrdinalBCELoss (:48-72), UncertaintyLoss (:80-101), KANRegressionLoss (:109-114).
- * Targets are int64 (torch.long).  NULL head pointers = head inactive at this curriculum stage.
+ * Class targets are int64 (torch.long), severity targets fp32 (the reference casts them with .float(), :89-90,
+ * :110-111; ordinal targets are (severity > k), :55-56).  A class label outside [0, num_classes) makes every loss NaN
+ * instead of reading out of bounds.  NULL head pointers = head inactive at this curriculum stage.
  * d_* = d(total)/d(head output) for an upstream gradient of 1; losses_out = [cls, ord, unc, kan, total].
  * rovit_scale_buffers multiplies up to 5 buffers by a device scalar (chain rule with the upstream gradient).
  * ------------------------------------------------------------------------------------------------------------ */
 int rovit_joint_loss(const float* cls_logits, const float* ordinal_logits, const float* mu, const float* log_var,
-                     const float* kan_severity, const long long* class_targets, const long long* severity_targets,
+                     const float* kan_severity, const long long* class_targets, const float* severity_targets,
                      const float* focal_alpha, float* d_cls, float* d_ord, float* d_mu, float* d_lv, float* d_kan,
                      float* losses_out, int batch, int num_classes, float lambda_ord, float mu_unc, float nu_kan, float focal_gamma,
                      rovit_stream_t stream);

@@ -132,6 +132,28 @@ def kan_module_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str
     return 3.0 * torch.sigmoid(x)
 
 
+def kan_module_layer_inputs(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str = '', degree: int = 3) -> List[torch.Tensor]:
+    """Inputs of every KAN layer of models/kan.py:138-149 (features, then the post-ReLU activations): the values whose
+    distance to the spline cutoff decides whether two precisions of the same features are comparable."""
+    xs, n = [], 0
+    while f'{prefix}kan_layers.{n}.spline_weights' in sd:
+        n += 1
+    for i in range(n):
+        xs.append(x)
+        p = f'{prefix}kan_layers.{i}.'
+        x = kan_layer_forward(x, sd[p + 'spline_weights'], sd[p + 'knots'], sd[p + 'linear.weight'], sd[p + 'linear.bias'], degree)
+        if i < n - 1:
+            x = torch.relu(x)
+    return xs
+
+
+def kan_cutoff(knots: torch.Tensor, degree: int = 3) -> float:
+    """The input value at which the reference's truncated basis jumps to zero: tanh(x) = knots[num_basis]
+    (models/kan.py:24,33-40)."""
+    nb = knots.numel() - degree - 1
+    return float(torch.atanh(knots[nb].double()))
+
+
 def init_kan_state(layers: List[int], num_knots: int = 5, degree: int = 3,
                    generator: Optional[torch.Generator] = None, prefix: str = '') -> Dict[str, torch.Tensor]:
     """Parameter shapes/initial distributions of models/kan.py:48-68,118-131."""
@@ -264,7 +286,7 @@ def init_vit_state(depth: int = VIT_DEPTH, generator: Optional[torch.Generator] 
 
 def vit_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str = '', heads: int = VIT_HEADS,
                 eps: float = 1e-6, return_tokens: bool = False, attn_taps: Optional[list] = None,
-                attn_probs: Optional[list] = None):
+                attn_probs: Optional[list] = None, tap_norm1: Optional[tuple] = None):
     """timm VisionTransformer.forward for deit_tiny_patch16_224, num_classes=0:
     patch conv k16/s16 -> [cls | patches] + pos_embed -> 12 pre-norm blocks -> LayerNorm -> token 0."""
     B = x.shape[0]
@@ -277,6 +299,9 @@ def vit_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str = '', 
     while f'{prefix}blocks.{i}.norm1.weight' in sd:
         b = f'{prefix}blocks.{i}.'
         h = F.layer_norm(t, (dim,), sd[b + 'norm1.weight'], sd[b + 'norm1.bias'], eps)
+        if tap_norm1 is not None and tap_norm1[0] == i:                # what hooks on blocks[i].norm1 see (reference
+            h = h.detach().requires_grad_(True)                        # explainability/gradcam.py:18-26,40): the output
+            tap_norm1[1]['y'] = h                                      # and, by autograd, the gradient w.r.t. it
         qkv = F.linear(h, sd[b + 'attn.qkv.weight'], sd[b + 'attn.qkv.bias'])
         qkv = qkv.reshape(B, -1, 3, heads, hd).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]

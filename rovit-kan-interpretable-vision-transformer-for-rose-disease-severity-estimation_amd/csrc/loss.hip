@@ -17,7 +17,7 @@ constexpr int MAXC = 16;
 
 struct LossArgs {
   const float* cls; const float* ord; const float* mu; const float* lv; const float* kan;
-  const long long* cls_t; const long long* sev_t; const float* alpha;
+  const long long* cls_t; const float* sev_t; const float* alpha;
   float* d_cls; float* d_ord; float* d_mu; float* d_lv; float* d_kan;
   float* out;      // [5]: cls, ord, unc, kan, total
   int B, C;
@@ -37,8 +37,13 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(const LossArgs a) {
   const float invB = 1.f / a.B;
   float l_cls = 0.f, l_ord = 0.f, l_unc = 0.f, l_kan = 0.f;
   for (int b = threadIdx.x; b < a.B; b += 256) {
-    const int t = (int)a.cls_t[b];
-    const float y = (float)a.sev_t[b];
+    // an out-of-range class label would index z[] / alpha[] out of bounds: clamp it and poison the losses with NaN so
+    // that the caller sees it (torch's cross_entropy raises a device assert in that case)
+    const long long t_raw = a.cls_t[b];
+    const bool t_ok = t_raw >= 0 && t_raw < a.C;
+    const int t = t_ok ? (int)t_raw : 0;
+    if (!t_ok) l_cls = __builtin_nanf("");
+    const float y = a.sev_t[b];                                    // severity as float, like the reference (:89-90, :110-111)
     // ---- focal cross-entropy (losses.py:15-38) ----
     float z[MAXC];
     float zmax = -INFINITY;
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(const LossArgs a) {
       float acc = 0.f;
       for (int k = 0; k < K1; ++k) {
         const float x = a.ord[(size_t)b * K1 + k];
-        const float yt = a.sev_t[b] > k ? 1.f : 0.f;
+        const float yt = y > (float)k ? 1.f : 0.f;                  // (targets > k).float(), losses.py:55-56
         acc += fmaxf(x, 0.f) - x * yt + __logf(1.f + __expf(-fabsf(x)));      // stable BCE-with-logits
         a.d_ord[(size_t)b * K1 + k] = w * (1.f / (1.f + __expf(-x)) - yt);
       }
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256) void scale_buffers_kernel(const ScaleArgs a) {
 // Inactive heads: pass NULL for (ord, d_ord) / (mu, lv, d_mu, d_lv) / (kan, d_kan) -- that is the curriculum gate.
 // d_* receive d(total)/d(output) for an upstream gradient of 1.  losses_out: [cls, ord, unc, kan, total].
 extern "C" int rovit_joint_loss(const float* cls_logits, const float* ordinal_logits, const float* mu, const float* log_var,
-                                const float* kan_severity, const long long* class_targets, const long long* severity_targets,
+                                const float* kan_severity, const long long* class_targets, const float* severity_targets,
                                 const float* focal_alpha, float* d_cls, float* d_ord, float* d_mu, float* d_lv, float* d_kan,
                                 float* losses_out, int batch, int num_classes, float lambda_ord, float mu_unc, float nu_kan,
                                 float focal_gamma, rovit_stream_t stream) {

@@ -182,6 +182,26 @@ extern "C" size_t rovit_vit_prep_bytes(int depth) { return Prep(depth).total; }
 extern "C" size_t rovit_vit_workspace_bytes(int batch, int depth, int training) { return Plan(batch, depth, training).total; }
 extern "C" int rovit_vit_num_params(int depth) { return P_BLOCK0 + B_COUNT * depth; }
 
+extern "C" int rovit_vit_workspace_field(int batch, int depth, int field, int block, size_t* offset, size_t* bytes) {
+  ROVIT_CHECK_ARG(offset && bytes, ROVIT_ERR_NULL, "vit_workspace_field: null output pointer");
+  ROVIT_CHECK_ARG(batch > 0 && depth > 0 && block >= 0 && block < depth, ROVIT_ERR_SHAPE, "vit_workspace_field: bad batch/depth/block");
+  const Plan L(batch, depth, 1);
+  const size_t blk = L.blk0 + (size_t)block * L.blk_stride, M = L.M;
+  switch (field) {
+    case ROVIT_WS_XHAT1: *offset = blk + L.xhat1; *bytes = M * D * 2; break;
+    case ROVIT_WS_RSTD1: *offset = blk + L.rstd1; *bytes = M * 4; break;
+    case ROVIT_WS_QKV: *offset = blk + L.qkv; *bytes = M * 3 * D * 2; break;
+    case ROVIT_WS_ATTN_O: *offset = blk + L.o; *bytes = M * D * 2; break;
+    case ROVIT_WS_XHAT2: *offset = blk + L.xhat2; *bytes = M * D * 2; break;
+    case ROVIT_WS_RSTD2: *offset = blk + L.rstd2; *bytes = M * 4; break;
+    case ROVIT_WS_ACT: *offset = blk + L.act; *bytes = M * MLP * 2; break;
+    // the last block's backward (CLS rows only behind the attention) uses buffer 0, the others their parity's
+    case ROVIT_WS_DQKV: *offset = L.dqkv[block == depth - 1 ? 0 : (block & 1)]; *bytes = M * 3 * D * 2; break;
+    default: rovit_set_error("vit_workspace_field: unknown field %d", field); return ROVIT_ERR_SHAPE;
+  }
+  return ROVIT_OK;
+}
+
 // Fold the LayerNorm affines, cast to bf16 and build the transposed copies the dgrad GEMMs read.
 // Must be re-run whenever the fp32 parameters change (every optimizer step).
 extern "C" int rovit_vit_prepare(const float* const* params, void* prep, int depth, rovit_stream_t stream) {

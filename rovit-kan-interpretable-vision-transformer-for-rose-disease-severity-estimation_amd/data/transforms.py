@@ -73,3 +73,55 @@ def cutmix_or_mixup(images: torch.Tensor, labels: torch.Tensor, use_cutmix: bool
     else:
         mixed = mix_images(images, perm, 'mixup', lam=lam)
     return mixed, labels, labels[perm], lam
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Per-image transforms.  The reference's scripts import ``augmented_transforms`` / ``original_transforms`` /
+# ``inference_transforms`` from this module (scripts/train.py:13, scripts/evaluate.py:11, scripts/run_ablation.py:12);
+# the module is absent from the reference checkout and torchvision is not installed here, so these are plain tensor
+# callables with the conventional behaviour (ImageNet normalisation; a random horizontal flip for training) --
+# "parity unpinned".  They accept (3,H,W) or (B,3,H,W) float tensors on any device.
+# ------------------------------------------------------------------------------------------------------------
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+class Normalize:
+    def __init__(self, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+        self.mean, self.std = torch.tensor(mean).view(3, 1, 1), torch.tensor(std).view(3, 1, 1)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        return (x - self.mean.to(x.device)) / self.std.to(x.device)
+
+
+class RandomHorizontalFlip:
+    def __init__(self, p: float = 0.5):
+        self.p = p
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() == 3:
+            return x.flip(-1) if float(torch.rand(())) < self.p else x
+        flip = torch.rand(x.shape[0], device=x.device) < self.p
+        return torch.where(flip.view(-1, 1, 1, 1), x.flip(-1), x)
+
+
+class Compose:
+    def __init__(self, fns):
+        self.fns = list(fns)
+
+    def __call__(self, x):
+        for f in self.fns:
+            x = f(x)
+        return x
+
+
+def augmented_transforms():
+    return Compose([RandomHorizontalFlip(0.5), Normalize()])
+
+
+def original_transforms():
+    return Compose([Normalize()])
+
+
+def inference_transforms():
+    return Compose([Normalize()])

@@ -14,37 +14,83 @@ EMBED_DIM, DEPTH, HEADS, MLP_DIM, PATCH, IMG = 192, 12, 3, 768, 16, 224
 TOKENS = (IMG // PATCH) ** 2 + 1
 
 
-class _PatchEmbed(nn.Module):
+_NO_HOOK = ('the HIP backbone runs blocks as fused kernels: a hook on `{name}` would never fire.  Supported taps: forward '
+            'hooks on `blocks[i].attn` and forward / full-backward hooks on `blocks[i].norm1` (fired from the fused path), '
+            '`DeiTTinyBackbone.get_attention_maps(x)`, `.get_attention_probabilities(x)` and rovit_hip.taps')
+
+
+class _NoHooks:
+    """Parameter containers whose forward is never called: registering a hook raises instead of silently not firing."""
+
+    def _refuse(self, *a, **k):
+        raise NotImplementedError(_NO_HOOK.format(name=type(self).__name__))
+
+    register_forward_hook = register_forward_pre_hook = register_full_backward_hook = _refuse
+    register_backward_hook = register_full_backward_pre_hook = _refuse
+
+
+class _Linear(_NoHooks, nn.Linear):
+    pass
+
+
+class _LayerNorm(_NoHooks, nn.LayerNorm):
+    pass
+
+
+class _Conv2d(_NoHooks, nn.Conv2d):
+    pass
+
+
+class _TapLayerNorm(nn.LayerNorm):
+    """norm1 of a block: forward hooks see its output (B,197,192), full-backward hooks the gradient w.r.t. that output
+    (what explainability/gradcam.py:18-26,40 registers on blocks[-1].norm1); both are fired by DeiTTiny.forward /
+    the fused backward from the kernels' saved buffers.  Other hook kinds cannot be honoured."""
+
+    def _refuse(self, *a, **k):
+        raise NotImplementedError(_NO_HOOK.format(name='norm1 (pre-hooks / non-full backward hooks)'))
+
+    register_forward_pre_hook = register_backward_hook = register_full_backward_pre_hook = _refuse
+
+
+class _PatchEmbed(_NoHooks, nn.Module):
     def __init__(self):
         super().__init__()
-        self.proj = nn.Conv2d(3, EMBED_DIM, kernel_size=PATCH, stride=PATCH)
+        self.proj = _Conv2d(3, EMBED_DIM, kernel_size=PATCH, stride=PATCH)
 
 
 class _Attention(nn.Module):
+    """Forward hooks see the module output (B,197,192), like timm's Attention under the reference's
+    get_attention_maps / AttentionRollout hooks (models/backbone.py:37-62, explainability/attention_maps.py:24-32)."""
+
     def __init__(self):
         super().__init__()
         self.num_heads = HEADS
         self.scale = (EMBED_DIM // HEADS) ** -0.5
-        self.qkv = nn.Linear(EMBED_DIM, 3 * EMBED_DIM, bias=True)
+        self.qkv = _Linear(EMBED_DIM, 3 * EMBED_DIM, bias=True)
         self.attn_drop = nn.Dropout(0.0)
-        self.proj = nn.Linear(EMBED_DIM, EMBED_DIM)
+        self.proj = _Linear(EMBED_DIM, EMBED_DIM)
         self.proj_drop = nn.Dropout(0.0)
 
+    def _refuse(self, *a, **k):
+        raise NotImplementedError(_NO_HOOK.format(name='attn (pre-hooks / backward hooks)'))
 
-class _Mlp(nn.Module):
+    register_forward_pre_hook = register_full_backward_hook = register_backward_hook = register_full_backward_pre_hook = _refuse
+
+
+class _Mlp(_NoHooks, nn.Module):
     def __init__(self):
         super().__init__()
-        self.fc1 = nn.Linear(EMBED_DIM, MLP_DIM)
+        self.fc1 = _Linear(EMBED_DIM, MLP_DIM)
         self.act = nn.GELU()
-        self.fc2 = nn.Linear(MLP_DIM, EMBED_DIM)
+        self.fc2 = _Linear(MLP_DIM, EMBED_DIM)
 
 
-class _Block(nn.Module):
+class _Block(_NoHooks, nn.Module):
     def __init__(self):
         super().__init__()
-        self.norm1 = nn.LayerNorm(EMBED_DIM, eps=1e-6)
+        self.norm1 = _TapLayerNorm(EMBED_DIM, eps=1e-6)
         self.attn = _Attention()
-        self.norm2 = nn.LayerNorm(EMBED_DIM, eps=1e-6)
+        self.norm2 = _LayerNorm(EMBED_DIM, eps=1e-6)
         self.mlp = _Mlp()
 
 
@@ -59,7 +105,7 @@ class DeiTTiny(nn.Module):
         self.pos_embed = nn.Parameter(torch.zeros(1, TOKENS, EMBED_DIM))
         self.patch_embed = _PatchEmbed()
         self.blocks = nn.ModuleList(_Block() for _ in range(depth))
-        self.norm = nn.LayerNorm(EMBED_DIM, eps=1e-6)
+        self.norm = _LayerNorm(EMBED_DIM, eps=1e-6)
         self._engine = None
         self.reset_parameters()
 
@@ -88,7 +134,44 @@ class DeiTTiny(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         training = torch.is_grad_enabled()
-        return VitFn.apply(x, self.engine, training, *self.ordered_parameters())
+        attn_hooked = [i for i, b in enumerate(self.blocks) if b.attn._forward_hooks]
+        norm_fwd = [i for i, b in enumerate(self.blocks) if b.norm1._forward_hooks]
+        norm_bwd = [i for i, b in enumerate(self.blocks) if b.norm1._backward_hooks]
+        if not (attn_hooked or norm_fwd or norm_bwd):
+            return VitFn.apply(x, self.engine, training, *self.ordered_parameters())
+        return self._forward_with_taps(x, training, attn_hooked, norm_fwd, norm_bwd)
+
+    def _forward_with_taps(self, x, training, attn_hooked, norm_fwd, norm_bwd):
+        """Hooks registered on blocks[i].attn / blocks[i].norm1 are fired from the fused path's own buffers
+        (rovit_hip/taps.py); a hook that returns a value (i.e. wants to REPLACE the activation) cannot be honoured."""
+        from rovit_hip import native, taps
+
+        def fire(module, hooks, *args):
+            for h in list(hooks.values()):
+                if h(module, *args) is not None:
+                    raise NotImplementedError('hooks on the fused backbone are observers: returning a replacement is not supported')
+        if attn_hooked:
+            outs = taps.attention_outputs(self, x.detach())          # one extra inference-mode forward
+            for i in attn_hooked:
+                fire(self.blocks[i].attn, self.blocks[i].attn._forward_hooks, (None,), outs[i])
+        eng = self.engine
+        if (norm_fwd or norm_bwd) and not (training and any(p.requires_grad for p in self.parameters())):
+            raise native.RovitHipError('hooks on blocks[i].norm1 read the training workspace: call the model with grad enabled '
+                                       'and trainable backbone parameters (as explainability/gradcam.py does)')
+        eng.grad_taps = {i: self._fire_norm1_backward for i in norm_bwd}
+        try:
+            feats = VitFn.apply(x, eng, training, *self.ordered_parameters())
+        finally:
+            eng.grad_taps = {}
+        for i in norm_fwd:
+            fire(self.blocks[i].norm1, self.blocks[i].norm1._forward_hooks, (None,), taps.norm1_output(self, i))
+        return feats
+
+    def _fire_norm1_backward(self, block: int, grad_output: torch.Tensor):
+        m = self.blocks[block].norm1
+        for h in list(m._backward_hooks.values()):
+            if h(m, (None,), (grad_output,)) is not None:
+                raise NotImplementedError('hooks on the fused backbone are observers: returning a replacement is not supported')
 
 
 class DeiTTinyBackbone(nn.Module):

@@ -194,6 +194,9 @@ class VitEngine:
         self.range_hook = None
         self.notify_stream: Optional[torch.cuda.Stream] = None
         self.pre_backward_hook = None    # called as hook(engine) when the backbone's backward starts (head/KAN grads are final)
+        # explainability: {block: callback(block, dL/d(norm1 output))}, set by DeiTTiny.forward for the next forward only
+        self.grad_taps = {}
+        self.last_ws = None              # (workspace, batch) of the most recent training-mode forward (read by rovit_hip.taps)
 
     # -- prepared weights ---------------------------------------------------------------------
     def prepare(self, params: Sequence[torch.Tensor]):
@@ -261,6 +264,9 @@ class VitFn(torch.autograd.Function):
         if need_bwd:
             ctx.ws = ws
             ctx.params = params
+            ctx.prep_key = engine._prep_key       # (data_ptr, version) of every parameter the bf16 weights were built from
+            ctx.grad_taps = dict(engine.grad_taps)
+            engine.last_ws = (ws, B)
         else:
             engine.give_ws(B, need_bwd, ws)
         return feats
@@ -271,6 +277,12 @@ class VitFn(torch.autograd.Function):
             return (None,) * (3 + ctx.engine.n_params)
         engine: VitEngine = ctx.engine
         params = ctx.params
+        if ctx.ws is None:
+            raise native.RovitHipError('backbone backward called twice on the same graph: the activation workspace is '
+                                       'recycled after the first backward (run the forward again instead of retain_graph=True)')
+        if engine._prep_key != ctx.prep_key:
+            raise native.RovitHipError('backbone parameters changed between forward and backward (optimizer step or '
+                                       'in-place update): the prepared bf16 weights no longer match the saved activations')
         dfeat = _f32c(dfeat)
         engine.ensure_grads(params)
         fresh = all(p.grad is None for p in params)
@@ -282,6 +294,18 @@ class VitFn(torch.autograd.Function):
         depth = engine.depth
         ranges = engine.backward_ranges or [(depth - 1, 0)]
         hooked = engine.range_hook is not None and fresh
+        grad_taps = ctx.grad_taps
+        if grad_taps:
+            # explainability taps: every tapped block ends a range of its own, so that its dqkv buffer can be read before
+            # block-2 reuses it; the data-parallel notify path is not combined with taps
+            cuts = sorted(grad_taps, reverse=True)
+            ranges, first = [], depth - 1
+            for c in cuts:
+                ranges.append((first, c))
+                first = c - 1
+            if first >= 0:
+                ranges.append((first, 0))
+            hooked = False
         if hooked and engine.pre_backward_hook is not None:
             engine.pre_backward_hook(engine)
         for first, last in ranges:
@@ -295,6 +319,9 @@ class VitFn(torch.autograd.Function):
                      first, last, stream_ptr())
                 if hooked:
                     engine.range_hook(engine, first, last, False)
+                if last in grad_taps:
+                    from . import taps
+                    grad_taps[last](last, taps.norm1_output_grad(params, ctx.ws, ctx.batch, depth, last))
         if fresh:
             for p, v in zip(params, engine.grad_views):
                 if p.requires_grad:
@@ -310,6 +337,8 @@ class VitFn(torch.autograd.Function):
             for p, v in zip(params, engine.stage_views):
                 if p.requires_grad:
                     p.grad = v.clone() if p.grad is None else p.grad.add_(v)
+        if engine.last_ws is not None and engine.last_ws[0] is ctx.ws:
+            engine.last_ws = None            # the workspace goes back to the pool: its saved activations are no longer valid
         engine.give_ws(ctx.batch, True, ctx.ws)
         ctx.ws = None
         return (None,) * (3 + engine.n_params)

@@ -26,7 +26,8 @@ class JointLossFn(torch.autograd.Function):
     def forward(ctx, cls, ordl, mu, lv, kan, cls_t, sev_t, alpha, weights):
         f = lambda t: None if t is None else t.detach().float().contiguous()
         cls, ordl, mu, lv, kan = f(cls), f(ordl), f(mu), f(lv), f(kan)
-        cls_t, sev_t = cls_t.long().contiguous(), sev_t.long().contiguous()
+        cls_t = cls_t.long().contiguous()
+        sev_t = sev_t.detach().float().reshape(-1).contiguous()      # severity stays float (reference losses.py:89-90,110-111)
         alpha = f(alpha.to(cls.device)) if alpha is not None else None
         B, C = cls.shape
         out = torch.empty(5, device=cls.device, dtype=torch.float32)
@@ -42,7 +43,10 @@ class JointLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_total, _g_comps):
-        grads = ctx.grads
+        if ctx.grads is None:
+            raise native.RovitHipError('JointLoss: backward called twice on the same graph (the fused kernel scales its '
+                                       'gradient buffers in place); call the loss again instead of retain_graph=True')
+        grads, ctx.grads = ctx.grads, None
         live = [g for g in grads if g is not None]
         arr = (ctypes.c_void_p * len(live))(*[g.data_ptr() for g in live])
         cnt = (ctypes.c_int * len(live))(*[g.numel() for g in live])
@@ -87,7 +91,7 @@ class JointLoss(nn.Module):
         losses['ord_loss'] = losses['unc_loss'] = losses['kan_loss'] = zero
         if ordl is not None:
             thr = torch.arange(ordl.shape[1], device=ordl.device)
-            bt = (severity_targets.unsqueeze(1) > thr).float()
+            bt = (sev.reshape(-1, 1) > thr).float()
             losses['ord_loss'] = F.binary_cross_entropy_with_logits(ordl, bt, reduction='none').mean(dim=1).mean()
             total = total + self.lambda_ord * losses['ord_loss']
         if mu is not None:

@@ -5,8 +5,10 @@ weight_decay 1e-4) and training/trainer.py:123-128,137-141 (clip_grad_norm_(para
 
 Every parameter is re-homed into a flat fp32 buffer (each nn.Parameter keeps its identity and becomes a view):
 * the backbone's 5.5 M parameters next to the flat gradient buffer the HIP backward already writes;
-* the ~0.18 M head / KAN parameters in a second buffer, one 16-byte-aligned segment per top-level module, whose
-  gradients (separate autograd tensors) are packed by one cat kernel per step.
+* the ~0.18 M head / KAN parameters in a second buffer, one segment per top-level module with EVERY parameter
+  starting on a 16-byte boundary (the head / KAN kernels read them with 16-byte loads and check the alignment; the
+  padding floats stay zero in the parameter, gradient and moment buffers, so norms and AdamW are unchanged); their
+  gradients (separate autograd tensors) are packed by one multi-tensor copy per step.
 The whole step is then: squared norms (rovit_sq_norm_accum per buffer) -> clip coefficient on the device
 (rovit_clip_coef) -> fused clip-scale + decoupled weight decay + Adam (rovit_adamw_flat per buffer / active segment).
 A module whose parameters received no gradient this step (curriculum stage gating) is skipped entirely, like
@@ -26,13 +28,23 @@ from . import native
 from .native import call, ptr, stream_ptr
 
 
+def _pad4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
 class _Segment:
-    """Parameters of one top-level module, contiguous in the flat buffer."""
+    """Parameters of one top-level module, contiguous in the flat buffer; every parameter starts on a 16-byte
+    boundary (offsets[i], relative to the flat buffer) and `numel` counts the padded extent."""
 
     def __init__(self, name: str, params: List[torch.nn.Parameter], offset: int):
         self.name, self.params, self.offset = name, params, offset
-        self.numel = sum(p.numel() for p in params)
+        self.offsets, o = [], offset
+        for p in params:
+            self.offsets.append(o)
+            o += _pad4(p.numel())
+        self.numel = o - offset
         self.t = 0
+        self.grad_views: List[torch.Tensor] = []
 
 
 class RoViTAdamW(torch.optim.Optimizer):
@@ -46,7 +58,13 @@ class RoViTAdamW(torch.optim.Optimizer):
         dev = self.bb_params[0].device
         if dev.type != 'cuda':
             raise native.RovitHipError('RoViTAdamW needs the model on a CUDA/HIP device (call model.to(device) first)')
-        self.p_flat = self._rehome(self.bb_params, [0], sum(p.numel() for p in self.bb_params), dev)
+        if any(p.numel() % 4 for p in self.bb_params):
+            raise native.RovitHipError('backbone parameters are expected to be multiples of 4 floats (16-byte aligned views)')
+        bb_offsets, o = [], 0
+        for p in self.bb_params:
+            bb_offsets.append(o)
+            o += p.numel()
+        self.p_flat = self._rehome(self.bb_params, bb_offsets, o, dev)
         self.m_flat = torch.zeros_like(self.p_flat)
         self.v_flat = torch.zeros_like(self.p_flat)
         self.t = 0
@@ -59,12 +77,14 @@ class RoViTAdamW(torch.optim.Optimizer):
         off = 0
         for name, ps in groups.items():
             self.segments.append(_Segment(name, ps, off))
-            off += (self.segments[-1].numel + 3) // 4 * 4
+            off += self.segments[-1].numel
         self.other_params = [p for s in self.segments for p in s.params]
         self.o_flat = torch.zeros(max(off, 4), dtype=torch.float32, device=dev)
         for s in self.segments:
-            self._rehome(s.params, [s.offset], s.numel, dev, self.o_flat)
+            self._rehome(s.params, s.offsets, s.numel, dev, self.o_flat)
         self.o_grad = torch.zeros_like(self.o_flat)
+        for s in self.segments:
+            s.grad_views = [self.o_grad[o:o + p.numel()].view_as(p) for o, p in zip(s.offsets, s.params)]
         self.o_m = torch.zeros_like(self.o_flat)
         self.o_v = torch.zeros_like(self.o_flat)
         super().__init__([{'params': list(self.bb_params), 'lr': lr / 10.0}, {'params': list(self.other_params), 'lr': lr}],
@@ -79,28 +99,31 @@ class RoViTAdamW(torch.optim.Optimizer):
     def _rehome(params, offsets, total, dev, flat=None):
         if flat is None:
             flat = torch.empty(total, dtype=torch.float32, device=dev)
-        off = offsets[0]
-        for p in params:
-            n = p.numel()
-            view = flat[off:off + n].view_as(p)
+        for off, p in zip(offsets, params):
+            view = flat[off:off + p.numel()].view_as(p)
             view.copy_(p.data)
             p.data = view
-            off += n
         return flat
 
     def _backbone_active(self) -> bool:
         return self.bb_params[0].requires_grad and self.bb_params[0].grad is not None
 
     def _pack_grads(self) -> List[_Segment]:
-        """Copy the active segments' gradients into o_grad (one cat kernel per run of fully populated segments)."""
-        active = []
+        """Copy the active segments' gradients into o_grad (one multi-tensor copy for all of them; the padding floats
+        between parameters are never written and stay zero)."""
+        active, dst, src = [], [], []
         for s in self.segments:
             grads = [p.grad for p in s.params]
             if all(g is None for g in grads):
                 continue
-            pieces = [(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(grads, s.params)]
-            torch.cat(pieces, out=self.o_grad[s.offset:s.offset + s.numel])
+            for v, g in zip(s.grad_views, grads):
+                if g is None:
+                    v.zero_()
+                else:
+                    dst.append(v); src.append(g)
             active.append(s)
+        if dst:
+            torch._foreach_copy_(dst, src)
         return active
 
     @torch.no_grad()
@@ -123,7 +146,7 @@ class RoViTAdamW(torch.optim.Optimizer):
                 call('rovit_sq_norm_accum', ptr(eng.grad_flat), eng.grad_flat.numel(), ptr(self._sq), ptr(self._sq_scratch), sp)
             for first, last in self._runs(active):      # padding floats of o_grad stay zero: sum whole aligned runs
                 call('rovit_sq_norm_accum', ptr(self.o_grad[first.offset:]),
-                     last.offset + (last.numel + 3) // 4 * 4 - first.offset, ptr(self._sq), ptr(self._sq_scratch), sp)
+                     last.offset + last.numel - first.offset, ptr(self._sq), ptr(self._sq_scratch), sp)
             call('rovit_clip_coef', ptr(self._sq), float(self.max_grad_norm), ptr(self._coef), ptr(self._norm), sp)
             self.last_grad_norm = self._norm
             coef = ptr(self._coef)
@@ -149,7 +172,7 @@ class RoViTAdamW(torch.optim.Optimizer):
         while i < len(active):
             j = i
             while (j + 1 < len(active) and (not same_t or active[j + 1].t == active[i].t) and
-                   active[j + 1].offset == active[j].offset + (active[j].numel + 3) // 4 * 4):
+                   active[j + 1].offset == active[j].offset + active[j].numel):
                 j += 1
             runs.append((active[i], active[j]))
             i = j + 1

@@ -95,7 +95,7 @@ class FlatBucketAllReduce:
 class GradSync:
     """Wires FlatBucketAllReduce into a RoViTKAN model: backbone buckets overlap with backward, heads/KAN after."""
 
-    def __init__(self, model, buckets: int = 3, group=None, force: bool = False):
+    def __init__(self, model, buckets: int = 3, group=None, force: bool = False, broadcast_init: bool = True):
         self.model = model
         self.engine = model.backbone.model.engine
         self.depth = model.backbone.model.depth
@@ -108,6 +108,8 @@ class GradSync:
         self.prefix = sum(sizes[:6])
         self.block_numel = sum(sizes[6:18])
         self.other_params = [p for n, p in model.named_parameters() if not n.startswith('backbone.')]
+        if self.active and broadcast_init and self.world > 1:
+            self.broadcast_parameters(group)
         if self.active:
             self.engine.backward_ranges = self.ranges
             self.engine.range_hook = self._on_range
@@ -115,6 +117,14 @@ class GradSync:
             dev = params[0].device
             if dev.type == 'cuda':
                 self.engine.notify_stream = self.reducer.stream_for(dev)
+
+    def broadcast_parameters(self, group=None):
+        """Replica identity does not depend on seeds or on which checkpoint a rank loaded: rank 0's parameters and
+        buffers (the KAN knots) are broadcast once, in place (views into flat optimizer buffers stay views)."""
+        with torch.no_grad():
+            for t in list(self.model.parameters()) + list(self.model.buffers()):
+                dist.broadcast(t.data, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self.engine._prep_key = None          # bf16 weights must be re-prepared from the received values
 
     def slice_for(self, first: int, last: int) -> Tuple[int, int]:
         off = self.prefix + last * self.block_numel

@@ -1,5 +1,6 @@
 """Explainability taps from the fused backbone."""
-from typing import List
+import ctypes
+from typing import List, Sequence
 
 import torch
 
@@ -44,3 +45,44 @@ def attention_probabilities(model, x: torch.Tensor) -> List[torch.Tensor]:
              eng.depth, stream_ptr())
     eng.give_ws(B, False, ws)
     return probs
+
+
+# ---- views into the training workspace (include/rovit_hip.h: rovit_vit_workspace_field) ------------------------
+WS_XHAT1, WS_RSTD1, WS_QKV, WS_ATTN_O, WS_XHAT2, WS_RSTD2, WS_ACT, WS_DQKV = range(8)
+_FIELD_DTYPE = {WS_XHAT1: (torch.bfloat16, 192), WS_QKV: (torch.bfloat16, 576), WS_ATTN_O: (torch.bfloat16, 192),
+                WS_XHAT2: (torch.bfloat16, 192), WS_ACT: (torch.bfloat16, 768), WS_DQKV: (torch.bfloat16, 576),
+                WS_RSTD1: (torch.float32, 1), WS_RSTD2: (torch.float32, 1)}
+
+
+def workspace_view(ws: torch.Tensor, batch: int, depth: int, field: int, block: int) -> torch.Tensor:
+    """Zero-copy (M, width) view of one saved buffer of a training workspace."""
+    off, nbytes = ctypes.c_size_t(), ctypes.c_size_t()
+    call('rovit_vit_workspace_field', batch, depth, field, block, ctypes.byref(off), ctypes.byref(nbytes))
+    dt, width = _FIELD_DTYPE[field]
+    return ws[off.value:off.value + nbytes.value].view(dt).view(batch * 197, width)
+
+
+def norm1_output(model, block: int) -> torch.Tensor:
+    """Output of ``blocks[block].norm1`` (B,197,192) of the most recent grad-mode forward: the kernels keep the
+    normalised rows xhat (bf16) for the backward; the affine is applied here (what a forward hook on norm1 sees,
+    reference explainability/gradcam.py:18-20,40)."""
+    eng = model.engine
+    if eng.last_ws is None:
+        raise native.RovitHipError('norm1_output: no training-mode forward is pending (run the model with grad enabled first)')
+    ws, B = eng.last_ws
+    blk = model.blocks[block]
+    xhat = workspace_view(ws, B, eng.depth, WS_XHAT1, block)
+    return (xhat.float() * blk.norm1.weight.detach() + blk.norm1.bias.detach()).view(B, 197, 192)
+
+
+def norm1_output_grad(params: Sequence[torch.Tensor], ws: torch.Tensor, batch: int, depth: int, block: int) -> torch.Tensor:
+    """dL/d(output of blocks[block].norm1), (B,197,192): the qkv dgrad against the UNFOLDED weight, computed by the
+    library's own GEMM from the dqkv buffer the fused backward has just written (valid right after
+    rovit_vit_backward(first_block=.., last_block=block); what a full-backward hook on norm1 sees, gradcam.py:22-26)."""
+    qkv_w = params[6 + 12 * block + 2]                       # ordered_parameters(): block i = [n1w, n1b, qkvw, ...]
+    wt = qkv_w.detach().t().contiguous().to(torch.bfloat16)  # (192, 576): row n holds d(qkv[:])/d(y[n])
+    dqkv = workspace_view(ws, batch, depth, WS_DQKV, block)
+    out = torch.empty(batch * 197, 192, device=ws.device, dtype=torch.bfloat16)
+    call('rovit_gemm_nt', ptr(dqkv), 576, ptr(wt), 576, batch * 197, 192, 576, None, 0, ptr(out), 192, None, None, 0, None, 0,
+         None, 0, stream_ptr())
+    return out.float().view(batch, 197, 192)

@@ -49,8 +49,9 @@ def test_backbone_forward_vs_hf_golden(golden_dir, name):
     rms = float((f - ref).pow(2).mean().sqrt())
     print(name, 'max|features - oracle| =', err, 'rms', rms)
     assert err < BF16_TOL and rms < BF16_RMS
-    if np.array_equal(x[0, :, :2, :4].numpy(), g['x_probe']):          # same generator stream as the fixture
-        assert float((f - torch.from_numpy(g['features'])).abs().max()) < BF16_TOL
+    # the committed HF-ViT features are only comparable on the fixture's own input: the probe pins the generator stream
+    assert np.array_equal(x[0, :, :2, :4].numpy(), g['x_probe']), 'generator stream differs from the one the fixture was made with'
+    assert float((f - torch.from_numpy(g['features'])).abs().max()) < BF16_TOL
 
 
 def test_backbone_backward_vs_oracle():
@@ -130,6 +131,7 @@ def test_full_model_forward_all_stages_vs_oracle():
         # class argmax: identical wherever the oracle's top-2 margin exceeds the stated tolerance
         top2 = ref['cls_logits'].topk(2, dim=1).values
         decided = (top2[:, 0] - top2[:, 1]) > 2 * BF16_TOL
+        print(f'stage {stage}: class argmax compared on {int(decided.sum())} of {decided.numel()} samples (oracle top-2 margin > {2 * BF16_TOL})')
         assert torch.equal(out['cls_logits'].cpu().argmax(1)[decided], ref['cls_logits'].argmax(1)[decided])
         # fp32 heads / KAN given the SAME features: north_star's 1e-3
         f = out['features'].cpu()

@@ -130,6 +130,12 @@ int rovit_vit_backward_notify(const float* d_features, const float* const* param
 int rovit_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, int epi, void* out,
                   int ldo, void* out2, float* xres, int ldx, const void* mul, int ldm, const float* pos, int tokens,
                   rovit_stream_t stream);
+/* First half of the MLP backward with gelu' recomputed (autograd of timm Mlp: fc2, GELU; reference reached through
+ * models/backbone.py:12-25 and training/trainer.py:119,136):
+ *   dpre (M,768) = (dY (M,192) W2T (768,192)^T) * gelu'( bf16( H (M,192) W1 (768,192)^T + b1 ) )
+ * H = xhat2 (the fc1 input), W1/b1 the fc1 weight with the norm2 affine folded in, W2T the transposed fc2 weight. */
+int rovit_gemm_mlp_bwd(const void* dY, int ldy, const void* H, int ldh, const void* W2T, const void* W1, const float* b1, int M,
+                       void* dpre, int ldo, rovit_stream_t stream);
 /* X(M,192) += bf16(A W^T + bias), fused with the LayerNorm that follows the residual add (timm Block: x = x + f(x);
  * norm(x)): xhat_out bf16 (M,192) and rstd_out (M) of the updated rows; xhat_out NULL = residual add only. */
 int rovit_gemm_resid_ln(const void* A, int lda, const void* W, int ldw, int M, int K, const float* bias, float* X, void* xhat_out,
@@ -138,6 +144,8 @@ int rovit_gemm_resid_ln(const void* A, int lda, const void* W, int ldw, int M, i
  * dxhat = dY W^T;  dX += rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat));  dXb = bf16(dX) */
 int rovit_gemm_ln_bwd(const void* dY, int ldy, const void* W, int ldw, int M, int K, const void* xhat, const float* rstd, float* dX,
                       void* dXb, rovit_stream_t stream);
+/* developer knob: output tile (tn x tk) of the weight-gradient kernel for A/B timing; 0,0 = library default per shape */
+int rovit_set_wgrad_tile(int tn, int tk);
 int rovit_set_gemm_debug(int flags); /* developer knob for timing ablations (tools/exp_*.py): bit 0 skip epilogue stores, bit 1 skip
                                        MFMAs, bit 2 skip steady-state LDS-DMA loads, bit 3 skip the GELU math; bits 4-5 = bits 0-1
                                        for the weight-gradient kernel.  Results are wrong with any bit set. */

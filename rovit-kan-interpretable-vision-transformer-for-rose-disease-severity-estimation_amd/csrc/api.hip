@@ -14,3 +14,20 @@ void rovit_set_error(const char* fmt, ...) {
 
 extern "C" int rovit_version(void) { return 100; }
 extern "C" const char* rovit_last_error_string(void) { return g_err; }
+
+#include <mutex>
+#include <utility>
+#include <vector>
+
+bool rovit_set_max_lds(const void* fn, size_t bytes) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  for (const auto& d : done)
+    if (d.first == fn && d.second == dev) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+  done.emplace_back(fn, dev);
+  return true;
+}

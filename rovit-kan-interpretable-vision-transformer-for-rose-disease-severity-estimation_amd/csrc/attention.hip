@@ -401,8 +401,7 @@ extern "C" int rovit_attention_fwd(const void* qkv, void* out, float* lse2, int 
   AttnArgs a{};
   a.qkv = (const bf16*)qkv; a.out = (bf16*)out; a.lse2 = lse2; a.T = tokens; a.H = heads; a.scale = scale;
   const size_t lds = (size_t)2 * TP * AST * sizeof(bf16);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)attn_fwd_kernel, lds), ROVIT_ERR_LAUNCH, "attention_fwd: cannot raise the LDS limit");
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(batch * heads), dim3(NW * 64), lds, (hipStream_t)stream, a);
   ROVIT_CHECK_LAUNCH("attn_fwd_kernel");
   return ROVIT_OK;
@@ -419,8 +418,7 @@ extern "C" int rovit_attention_bwd(const void* qkv, const void* out, const float
   a.qkv = (const bf16*)qkv; a.out = (bf16*)out; a.lse2 = (float*)lse2; a.T = tokens; a.H = heads; a.scale = scale;
   a.dout = (const bf16*)dout; a.dqkv = (bf16*)dqkv;
   const size_t lds = (size_t)4 * TP * AST * sizeof(bf16) + 2 * TP * sizeof(float);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)attn_bwd_kernel, lds), ROVIT_ERR_LAUNCH, "attention_bwd: cannot raise the LDS limit");
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(batch * heads), dim3(NW * 64), lds, (hipStream_t)stream, a);
   ROVIT_CHECK_LAUNCH("attn_bwd_kernel");
   return ROVIT_OK;

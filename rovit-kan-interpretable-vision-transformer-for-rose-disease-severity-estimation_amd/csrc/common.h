@@ -34,6 +34,10 @@ void rovit_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: (kernel, device) pairs are remembered,
+// not a process-wide flag, so a second device in the same process gets its attribute too (api.hip)
+bool rovit_set_max_lds(const void* fn, size_t bytes);
+
 static inline bool rovit_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- device helpers ------------------------------------------------------------------

@@ -27,6 +27,8 @@
 
 namespace {
 
+inline bool set_max_lds(const void* fn, size_t bytes) { return rovit_set_max_lds(fn, bytes); }
+
 constexpr int BK = 64;
 constexpr int LDS_STRIDE = BK + 16;      // bf16 elements; 160-byte rows: conflict-free ds_read_b128 fragments
 
@@ -64,6 +66,18 @@ __device__ __forceinline__ void gelu_and_grad(float x, float& act, float& dact) 
   const float cdf = 0.5f + copysignf(half_erf, x);
   act = x * cdf;
   dact = fmaf(x * 0.3989422804014327f, e, cdf);
+}
+
+// the derivative alone (same formulas, one multiply less)
+__device__ __forceinline__ float gelu_grad(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189303853130f, fabsf(x), 1.f));
+  float p = fmaf(0.5306027145f, t, -0.7265760135f);
+  p = fmaf(p, t, 0.7107068705f);
+  p = fmaf(p, t, -0.142248368f);
+  p = fmaf(p, t, 0.127414796f);
+  const float cdf = 0.5f + copysignf(fmaf(-p * t, e, 0.5f), x);
+  return fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
 template <int EPI>
@@ -546,7 +560,7 @@ __global__ __launch_bounds__(256 * WK, 2) void gemm_ws_kernel(const GemmArgs g, 
 
 // CUs a weight-stationary launch sizes its grid for (256 = the whole chip).  The two-stream forward halves it so that
 // the kernels of the two half-batch chains co-reside instead of queueing behind each other.
-static int g_cu_budget = 256;
+static thread_local int g_cu_budget = 256;      // per host thread: one thread drives one device
 
 template <int KS, int WK, int BM>
 int launch_ws(const GemmArgs& g0, int epi, hipStream_t st) {
@@ -569,11 +583,9 @@ int launch_ws(const GemmArgs& g0, int epi, hipStream_t st) {
   dim3 grid(P * g.n_tiles), block(256 * WK);
 #define LAUNCHW(E)                                                                                        \
   case E: {                                                                                               \
-    static bool attr_set = false;                                                                         \
-    if (!attr_set) {                                                                                      \
-      (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<KS, WK, BM, E>,                               \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
-      attr_set = true;                                                                                    \
+    if (!set_max_lds((const void*)gemm_ws_kernel<KS, WK, BM, E>, lds)) {                                  \
+      rovit_set_error("gemm_ws: cannot raise the LDS limit");                                             \
+      return ROVIT_ERR_LAUNCH;                                                                            \
     }                                                                                                     \
     hipLaunchKernelGGL((gemm_ws_kernel<KS, WK, BM, E>), grid, block, lds, st, g, tpw, tiles_m);           \
     break;                                                                                                \
@@ -776,13 +788,181 @@ int launch_ws_dma(const GemmArgs& g0, hipStream_t st) {
   int P = (tiles_m + tpw - 1) / tpw;
   P = (P + 7) / 8 * 8;
   const size_t lds = (size_t)(EPI == EPI_MUL ? 6 : 3) * BM * 192 * sizeof(bf16);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_ws_dma_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  ROVIT_CHECK_ARG(set_max_lds((const void*)gemm_ws_dma_kernel<EPI>, lds), ROVIT_ERR_LAUNCH, "gemm_ws_dma: cannot raise the LDS limit");
   hipLaunchKernelGGL((gemm_ws_dma_kernel<EPI>), dim3(P * g.n_tiles), dim3(256), lds, st, g, tpw, tiles_m);
   ROVIT_CHECK_LAUNCH("gemm_ws_dma_kernel");
+  return ROVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// MLP backward, first half, with gelu' RECOMPUTED instead of read (round 2):
+//     dpre[M,768] = (dY[M,192] W2T[768,192]^T)  *  gelu'( bf16( xhat2[M,192] W1[768,192]^T + b1 ) )
+// The forward no longer writes gelu'(pre) (77 MB per block at batch 256) and this kernel reads the 19 MB of xhat2
+// instead of those 77 MB: 174 -> 115 MB per launch, and the forward's fc1 GEMM drops from 174 to 97 MB.
+// Same skeleton as gemm_ws_dma_kernel: both operand tiles (64 x 192) come in by LDS-DMA through two 3-slot rings
+// (144 KB, one workgroup per CU), the weights are register-stationary.  TWELVE waves each own 16 output columns of
+// the workgroup's 192-column chunk for BOTH products (2 x 24 registers of weights), so a lane ends up holding pre and
+// dY.W2T for the same 4 columns of a row and the product needs no exchange.  pre is rounded to bf16 before gelu'
+// because that is the value the forward's GELU saw (its tile is staged in bf16).
+// ------------------------------------------------------------------------------------------------------
+struct MlpBwdArgs {
+  const bf16* dY; int ldy;        // (M,192) gradient w.r.t. the MLP output
+  const bf16* H; int ldh;         // (M,192) xhat2, the fc1 input
+  const bf16* W2T;                // (768,192) fc2 weight transposed: row n = d(out[:])/d(act[n])
+  const bf16* W1;                 // (768,192) fc1 weight with the norm2 affine folded in
+  const float* b1;                // (768) fc1 bias (folded)
+  bf16* out; int ldo;             // (M,768) dpre
+  int M, n_tiles;
+};
+
+// NW waves each own 192 / NW output columns of the workgroup's chunk for BOTH products; BM rows per tile.
+//   <64, 12>: one 12-wave workgroup per CU (144 KB of LDS);  <32, 6>: two 6-wave workgroups per CU (72 KB each), whose
+//   phases (DMA wait / MFMA / gelu' / store) interleave -- the epilogue is VALU-heavy (one exp2 + one rcp per element).
+template <int BM, int NW>
+__global__ __launch_bounds__(NW * 64, 3) void mlp_bwd_dma_kernel(const MlpBwdArgs g, int tiles_per_wg, int n_tiles_m) {
+  constexpr int KS = 6, K = 192, TM = BM / 16, NT = NW * 64;
+  constexpr int JT = 192 / NW / 16;                         // 16-column tiles per wave
+  constexpr int SLOT = BM * K;
+  constexpr int NPIECE = BM * 24 / 64;                      // 1 KB DMA pieces per tile and ring
+  constexpr int PW = NPIECE / NW;                           // ... per wave
+  constexpr int PIECES = 2 * PW;                            // DMA instructions one wave issues per tile (both rings)
+  constexpr int SMAX = BM * 24 / NT;                        // global stores one thread issues per tile
+  static_assert(NPIECE % NW == 0 && (BM * 24) % NT == 0 && 192 % (NW * 16) == 0, "tile must split evenly");
+  extern __shared__ __attribute__((aligned(16))) bf16 lds[];   // ring[6][BM][192]: slots 0-2 dY, 3-5 xhat2; ONE array
+
+  const int nchunks = g.n_tiles;
+  const int bid = blockIdx.x;
+  const int chunk = (bid >> 3) % nchunks;                   // the chunks of one row range share an XCD (ids b, b+8, ...)
+  const int p = (bid / (8 * nchunks)) * 8 + (bid & 7);
+  const int tile0 = p * tiles_per_wg;
+  int ntile = n_tiles_m - tile0;
+  ntile = ntile > tiles_per_wg ? tiles_per_wg : ntile;
+  if (ntile <= 0) return;
+  const int n0 = chunk * 192;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  // DMA pieces of this wave: piece j = wave + NW i covers linear 16-byte chunks 64 j + lane of a slot
+  int d_row[PW], d_col[PW];
+#pragma unroll
+  for (int i = 0; i < PW; ++i) {
+    const int c = 64 * (wave + NW * i) + lane;
+    const int r = c / 24, x = c - r * 24;
+    d_row[i] = r;
+    d_col[i] = ((x & ~7) | ((x & 7) ^ ((r >> 1) & 7))) * 8;
+  }
+  auto dma = [&](int tile, int slot) {
+    const int row0 = tile * BM;
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      int gr = row0 + d_row[i];
+      gr = gr < g.M ? gr : g.M - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.dY + (size_t)gr * g.ldy + d_col[i]),
+                                       (__attribute__((address_space(3))) void*)(lds + slot * SLOT + (wave + NW * i) * 512), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      int gr = row0 + d_row[i];
+      gr = gr < g.M ? gr : g.M - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.H + (size_t)gr * g.ldh + d_col[i]),
+                                       (__attribute__((address_space(3))) void*)(lds + (3 + slot) * SLOT + (wave + NW * i) * 512), 16, 0, 0);
+    }
+  };
+  dma(tile0, 0);
+  if (ntile > 1) dma(tile0 + 1, 1);
+  if (ntile > 2) dma(tile0 + 2, 2);
+
+  // stationary fragments of both weights: output column n0 + 16 (JT wave + j) + l15, k = 32 ks + 8 lg
+  bf16x8 w2[JT][KS], w1[JT][KS];
+  f32x4 bias4[JT];
+#pragma unroll
+  for (int j = 0; j < JT; ++j) {
+    const int col = n0 + 16 * (JT * wave + j);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      w2[j][ks] = *(const bf16x8*)(g.W2T + (size_t)(col + l15) * K + ks * 32 + lg * 8);
+      w1[j][ks] = *(const bf16x8*)(g.W1 + (size_t)(col + l15) * K + ks * 32 + lg * 8);
+    }
+    const float4 bb = *(const float4*)(g.b1 + col + 4 * lg);
+    bias4[j] = (f32x4){bb.x, bb.y, bb.z, bb.w};
+  }
+  const int swz = (l15 >> 1) & 7;
+  const int xo0 = ((0 + lg) ^ swz) * 8, xo1 = ((4 + lg) ^ swz) * 8;
+  const int frag_row = l15 * K;
+
+  for (int t = 0; t < ntile; ++t) {
+    const int slot = t % 3;
+    // tile t has landed once at most (DMA(t+1) + the stores of tile t-1) are outstanding (issue order per iteration:
+    // [DMA(t+2)] [stores(t)]); only the LAST tile of a launch can be partial, and it waits for everything
+    if (t + 2 < ntile) {
+      if (t == 0) wait_vmcnt<2 * PIECES>(); else wait_vmcnt<PIECES + SMAX>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (t >= 1 && t + 2 < ntile) dma(tile0 + t + 2, (t + 2) % 3);
+
+    f32x4 pre[TM][JT], dac[TM][JT];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < JT; ++j) { pre[i][j] = bias4[j]; dac[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const bf16* Ya = lds + slot * SLOT + frag_row;
+    const bf16* Ha = lds + (3 + slot) * SLOT + frag_row;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int off = (ks >> 1) * 64 + ((ks & 1) ? xo1 : xo0);
+      bf16x8 fy[TM], fh[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) { fh[i] = *(const bf16x8*)(Ha + i * 16 * K + off); fy[i] = *(const bf16x8*)(Ya + i * 16 * K + off); }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) { pre[i][j] = mfma16(w1[j][ks], fh[i], pre[i][j]); dac[i][j] = mfma16(w2[j][ks], fy[i], dac[i][j]); }   // D[n][m]
+    }
+    barrier_lds();                                    // all fragment reads of both slots are done: reuse the dY slot for the output tile
+    bf16* Cs = lds + slot * SLOT;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = dac[i][j][r] * gelu_grad((float)(bf16)pre[i][j][r]);   // GELU saw the bf16-staged pre-activation
+        const int row = i * 16 + l15;
+        const int ch = 2 * (JT * wave + j) + (lg >> 1);
+        const int phys = (ch & ~7) | ((ch & 7) ^ (row & 7));
+        *(bf16x4*)(Cs + row * K + phys * 8 + 4 * (lg & 1)) = pack4(o);
+      }
+    barrier_lds();
+    const int mbase = (tile0 + t) * BM;
+#pragma unroll
+    for (int q = 0; q < SMAX; ++q) {
+      const int c = tid + q * NT;
+      const int row = c / 24, ch = c - row * 24;
+      const int m = mbase + row;
+      if (m < g.M) {
+        const int phys = (ch & ~7) | ((ch & 7) ^ (row & 7));
+        *(bf16x8*)(g.out + (size_t)m * g.ldo + n0 + ch * 8) = *(const bf16x8*)(Cs + row * K + phys * 8);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the next top barrier retires this tile before its slot is refilled
+  }
+}
+
+template <int BM, int NW>
+int launch_mlp_bwd(const MlpBwdArgs& g, hipStream_t st) {
+  const int tiles_m = (g.M + BM - 1) / BM;
+  int pmax = g_cu_budget * (768 / (NW * 64)) / g.n_tiles;     // workgroups per CU that fit the 6-slot ring
+  pmax = pmax < 8 ? 8 : pmax / 8 * 8;
+  const int tpw = (tiles_m + pmax - 1) / pmax;
+  int P = (tiles_m + tpw - 1) / tpw;
+  P = (P + 7) / 8 * 8;
+  const size_t lds = (size_t)6 * BM * 192 * sizeof(bf16);
+  ROVIT_CHECK_ARG(set_max_lds((const void*)mlp_bwd_dma_kernel<BM, NW>, lds), ROVIT_ERR_LAUNCH, "gemm_mlp_bwd: cannot raise the LDS limit");
+  hipLaunchKernelGGL((mlp_bwd_dma_kernel<BM, NW>), dim3(P * g.n_tiles), dim3(NW * 64), lds, st, g, tpw, tiles_m);
+  ROVIT_CHECK_LAUNCH("mlp_bwd_dma_kernel");
   return ROVIT_OK;
 }
 
@@ -984,11 +1164,7 @@ int launch_kdma(const GemmArgs& g0, hipStream_t st) {
   const int tpw = (tiles_m + pmax - 1) / pmax;
   const int P = (tiles_m + tpw - 1) / tpw;
   const size_t lds = (size_t)3 * BM * 32 * KT * sizeof(bf16);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_kdma_kernel<KT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  ROVIT_CHECK_ARG(set_max_lds((const void*)gemm_kdma_kernel<KT, EPI>, lds), ROVIT_ERR_LAUNCH, "gemm_kdma: cannot raise the LDS limit");
   hipLaunchKernelGGL((gemm_kdma_kernel<KT, EPI>), dim3(P), dim3(768), lds, st, g, tpw, tiles_m);
   ROVIT_CHECK_LAUNCH("gemm_kdma_kernel");
   return ROVIT_OK;
@@ -1008,11 +1184,9 @@ int launch_nt(const GemmArgs& g0, int epi, hipStream_t st) {
   dim3 grid(nwg), block(WM * WN * 64);
 #define LAUNCH(E)                                                                                         \
   case E: {                                                                                               \
-    static bool attr_set = false;                                                                         \
-    if (!attr_set) {                                                                                      \
-      (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, WM, WN, E>,                           \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
-      attr_set = true;                                                                                    \
+    if (!set_max_lds((const void*)gemm_nt_kernel<BM, BN, WM, WN, E>, lds)) {                              \
+      rovit_set_error("gemm_nt: cannot raise the LDS limit");                                             \
+      return ROVIT_ERR_LAUNCH;                                                                            \
     }                                                                                                     \
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, E>), grid, block, lds, st, g);                     \
     break;                                                                                                \
@@ -1033,9 +1207,10 @@ int launch_nt(const GemmArgs& g0, int epi, hipStream_t st) {
 // LDS tiles.  Contraction slot (group g, element j) of a 32-row step holds row 16*(j>>2) + 4*g + (j&3):
 // the two 16-lane groups of a half-wave then read 8 consecutive LDS rows (conflict-free at a 224-byte stride).
 // ------------------------------------------------------------------------------------------------------
-constexpr int WG_T = 96;                      // output tile edge (n and k)
 constexpr int WG_MSTEP = 64;
-constexpr int WG_STRIDE = WG_T + 16;          // 224-byte rows
+// LDS row stride (bf16 elements) of a [rows][T] operand tile: T + 16 or T + 32 so that the stride is an ODD multiple of 32 bytes
+// (conflict-free ds_read_b64_tr_b16: the two 16-lane groups of a half-wave read 8 consecutive rows)
+constexpr int wg_stride(int t) { return ((t + 16) * 2 / 32) % 2 ? t + 16 : t + 32; }
 
 struct WgradArgs {
   const bf16* dY; int ldy;
@@ -1049,116 +1224,136 @@ struct WgradArgs {
   int dbg;              // developer knob: bit 0 skip steady-state global loads, bit 1 skip MFMAs
 };
 
-template <bool PATCH>
+// Output tile TN (columns of dY = rows n of G) x TK (columns of A = columns k of G) per workgroup; four waves as 2 (k) x 2 (n),
+// wave tile TK/2 x TN/2.  Smaller tiles mean fewer M-splits for the same number of workgroups, i.e. fewer fp32 partial
+// slabs to write and reduce (slab bytes = splits x N x K x 4), at the price of more operand re-reads through the XCD's
+// L2 (every tile of a split streams the same rows; all tiles of a split run on one XCD).
+template <int TN, int TK, bool PATCH>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
-  constexpr int CPR = WG_T / 8;                         // 12 chunks per row
-  constexpr int CH = WG_MSTEP * CPR / 256;              // 3 chunks per thread per operand
-  __shared__ __attribute__((aligned(16))) bf16 lds[2 * 2 * WG_MSTEP * WG_STRIDE];
-  bf16* Ys = lds;                                       // [2][MSTEP][STRIDE]
-  bf16* As = lds + 2 * WG_MSTEP * WG_STRIDE;
+  constexpr int SY = wg_stride(TN), SA = wg_stride(TK);
+  constexpr int CPRY = TN / 8, CPRA = TK / 8;           // 16-byte chunks per tile row
+  constexpr int CHY = WG_MSTEP * CPRY / 256, CHA = WG_MSTEP * CPRA / 256;   // chunks per thread and step
+  constexpr int JN = TN / 32, IK = TK / 32;             // 16 x 16 accumulator tiles per wave: IK (k) x JN (n)
+  static_assert(TN % 32 == 0 && TK % 32 == 0, "wave tiles are multiples of 16");
+  __shared__ __attribute__((aligned(16))) bf16 lds[2 * WG_MSTEP * (SY + SA)];
+  bf16* Ys = lds;                                       // [2][MSTEP][SY]
+  bf16* As = lds + 2 * WG_MSTEP * SY;                   // [2][MSTEP][SA]
 
   const int tiles = g.k_tiles * g.n_tiles;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);            // all tiles of a split on one XCD
   const int split = bid / tiles, tile = bid - split * tiles;
   if (split >= g.splits) return;
   const int ntile = tile / g.k_tiles, ktile = tile - ntile * g.k_tiles;
-  const int n0 = ntile * WG_T, k0 = ktile * WG_T;
+  const int n0 = ntile * TN, k0 = ktile * TK;
   const int m_begin = split * g.rows_per_split;
   const int m_end = min(g.M, m_begin + g.rows_per_split);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wk = wave >> 1, wn = wave & 1;              // wave tile: k rows [48*wk, +48), n cols [48*wn, +48)
+  const int wk = wave >> 1, wn = wave & 1;              // wave tile: k rows [TK/2*wk, +TK/2), n cols [TN/2*wn, +TN/2)
   const int l15 = lane & 15, lg = lane >> 4;
 
   // Per-thread staging chunks.  Keep the hot loop free of address arithmetic: one clamped row index and one
   // 64-bit multiply-add per chunk and step; the LDS offsets are loop constants.
-  int c_row[CH], c_lds[CH];
-  const bf16* ybase[CH];
-  const bf16* abase[CH];
+  int y_row[CHY], y_lds[CHY], a_row[CHA], a_lds[CHA];
+  const bf16* ybase[CHY];
+  const bf16* abase[CHA];
 #pragma unroll
-  for (int i = 0; i < CH; ++i) {
+  for (int i = 0; i < CHY; ++i) {
     const int c = tid + i * 256;
-    c_row[i] = c / CPR;
-    const int col = (c - c_row[i] * CPR) * 8;
-    c_lds[i] = c_row[i] * WG_STRIDE + col;
+    y_row[i] = c / CPRY;
+    const int col = (c - y_row[i] * CPRY) * 8;
+    y_lds[i] = y_row[i] * SY + col;
     ybase[i] = g.dY + n0 + col;
+  }
+#pragma unroll
+  for (int i = 0; i < CHA; ++i) {
+    const int c = tid + i * 256;
+    a_row[i] = c / CPRA;
+    const int col = (c - a_row[i] * CPRA) * 8;
+    a_lds[i] = a_row[i] * SA + col;
     abase[i] = g.A + k0 + col;
   }
   const int m_last = g.M - 1;
   auto load = [&](int mbase, bf16x8* ry, bf16x8* ra) {
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      int m = mbase + c_row[i];
+    for (int i = 0; i < CHY; ++i) {
+      int m = mbase + y_row[i];
       m = m < m_last ? m : m_last;                      // clamp (never branch around a load); tail rows are zeroed in store()
       const int yr = PATCH ? m + m / (g.patch_tokens - 1) + 1 : m;
       ry[i] = *(const bf16x8*)(ybase[i] + (size_t)yr * g.ldy);
+    }
+#pragma unroll
+    for (int i = 0; i < CHA; ++i) {
+      int m = mbase + a_row[i];
+      m = m < m_last ? m : m_last;
       ra[i] = *(const bf16x8*)(abase[i] + (size_t)m * g.lda);
     }
   };
   auto store = [&](int buf, int mbase, const bf16x8* ry, const bf16x8* ra) {
-    bf16* yd = Ys + buf * WG_MSTEP * WG_STRIDE;
-    bf16* ad = As + buf * WG_MSTEP * WG_STRIDE;
+    bf16* yd = Ys + buf * WG_MSTEP * SY;
+    bf16* ad = As + buf * WG_MSTEP * SA;
     if (mbase + WG_MSTEP <= m_end) {                    // wave-uniform: full step
 #pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        *(bf16x8*)(yd + c_lds[i]) = ry[i];
-        *(bf16x8*)(ad + c_lds[i]) = ra[i];
-      }
+      for (int i = 0; i < CHY; ++i) *(bf16x8*)(yd + y_lds[i]) = ry[i];
+#pragma unroll
+      for (int i = 0; i < CHA; ++i) *(bf16x8*)(ad + a_lds[i]) = ra[i];
     } else {                                            // last, partial step of a split: zero the rows past m_end
 #pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const bool live = mbase + c_row[i] < m_end;
-        *(bf16x8*)(yd + c_lds[i]) = keep_if(ry[i], live);
-        *(bf16x8*)(ad + c_lds[i]) = keep_if(ra[i], live);
-      }
+      for (int i = 0; i < CHY; ++i) *(bf16x8*)(yd + y_lds[i]) = keep_if(ry[i], mbase + y_row[i] < m_end);
+#pragma unroll
+      for (int i = 0; i < CHA; ++i) *(bf16x8*)(ad + a_lds[i]) = keep_if(ra[i], mbase + a_row[i] < m_end);
     }
   };
 
-  f32x4 acc[3][3], accb[3];
+  f32x4 acc[IK][JN], accb[JN];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < JN; ++j) {
+    accb[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < IK; ++i) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   bf16x8 ones;
 #pragma unroll
   for (int q = 0; q < 8; ++q) ones[q] = (bf16)1.0f;
   // bias gradient: one extra MFMA per 16 columns against a tile of ones.  The waves that hold the same dY
-  // fragments (same n-tile: 2 wk x k_tiles workgroups) share the three column tiles between them.
+  // fragments (same n-tile: 2 wk x k_tiles workgroups) share the column tiles between them.
   const int cs_owner = ktile * 2 + wk, cs_n = 2 * g.k_tiles;
-  const bool cs_do[3] = {0 % cs_n == cs_owner, 1 % cs_n == cs_owner, 2 % cs_n == cs_owner};
+  bool cs_do[JN];
+#pragma unroll
+  for (int j = 0; j < JN; ++j) cs_do[j] = (j % cs_n) == cs_owner;
 
   const int nsteps = (m_end - m_begin + WG_MSTEP - 1) / WG_MSTEP;
-  // transposed-read lane address inside a [rows][WG_STRIDE] tile: row 4*lg + (l15>>2), col 4*(l15&3)
-  const int tr_off = (4 * lg + (l15 >> 2)) * WG_STRIDE + 4 * (l15 & 3);
-  const bf16* Ybase = Ys + tr_off + wn * 48;
-  const bf16* Abase = As + tr_off + wk * 48;
+  // transposed-read lane address inside a [rows][stride] tile: row 4*lg + (l15>>2), col 4*(l15&3)
+  const bf16* Ybase = Ys + (4 * lg + (l15 >> 2)) * SY + 4 * (l15 & 3) + wn * (TN / 2);
+  const bf16* Abase = As + (4 * lg + (l15 >> 2)) * SA + 4 * (l15 & 3) + wk * (TK / 2);
   auto compute = [&](int cur) {
-    const bf16* Yc = Ybase + cur * WG_MSTEP * WG_STRIDE;
-    const bf16* Ac = Abase + cur * WG_MSTEP * WG_STRIDE;
+    const bf16* Yc = Ybase + cur * WG_MSTEP * SY;
+    const bf16* Ac = Abase + cur * WG_MSTEP * SA;
 #pragma unroll
     for (int ms = 0; ms < WG_MSTEP / 32; ++ms) {
-      bf16x8 fa[3], fy[3];
+      bf16x8 fa[IK], fy[JN];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const bf16* p = Ac + ms * 32 * WG_STRIDE + i * 16;
-        fa[i] = cat4(lds_read_tr(p), lds_read_tr(p + 16 * WG_STRIDE));
-        const bf16* q = Yc + ms * 32 * WG_STRIDE + i * 16;
-        fy[i] = cat4(lds_read_tr(q), lds_read_tr(q + 16 * WG_STRIDE));
+      for (int i = 0; i < IK; ++i) {
+        const bf16* p = Ac + ms * 32 * SA + i * 16;
+        fa[i] = cat4(lds_read_tr(p), lds_read_tr(p + 16 * SA));
       }
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < JN; ++j) {
+        const bf16* q = Yc + ms * 32 * SY + j * 16;
+        fy[j] = cat4(lds_read_tr(q), lds_read_tr(q + 16 * SY));
+      }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(fa[i], fy[j], acc[i][j]);      // D[k][n]
+      for (int i = 0; i < IK; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < JN; ++j) acc[i][j] = mfma16(fa[i], fy[j], acc[i][j]);      // D[k][n]
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
         if (cs_do[j]) accb[j] = mfma16(ones, fy[j], accb[j]);
     }
   };
   // Two register sets keep the global loads of steps s+1 and s+2 in flight while step s runs its MFMAs; the
   // barrier waits for LDS only, so those loads are not drained at it.
-  bf16x8 ryA[CH], raA[CH], ryB[CH], raB[CH];
+  bf16x8 ryA[CHY], raA[CHA], ryB[CHY], raB[CHA];
   load(m_begin, ryA, raA);
   store(0, m_begin, ryA, raA);
   load(m_begin + WG_MSTEP, ryA, raA);
@@ -1179,11 +1374,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   }
   float* slab = g.slab + (size_t)split * g.N * g.K;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int n = n0 + wn * 48 + j * 16 + l15;
+  for (int j = 0; j < JN; ++j) {
+    const int n = n0 + wn * (TN / 2) + j * 16 + l15;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int k = k0 + wk * 48 + i * 16 + lg * 4;
+    for (int i = 0; i < IK; ++i) {
+      const int k = k0 + wk * (TK / 2) + i * 16 + lg * 4;
       *(float4*)(slab + (size_t)n * g.K + k) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     }
     if (cs_do[j] && lg == 0) g.colsum[(size_t)split * g.N + n] = accb[j][0];
@@ -1317,12 +1512,45 @@ extern "C" int rovit_gemm_nt(const void* A, int lda, const void* W, int ldw, int
   return launch_nt<128, 96, 2, 2>(g, epi, (hipStream_t)stream);
 }
 
+// dpre = (dY W2T^T) * gelu'(bf16(H W1^T + b1)): first half of the MLP backward with gelu' recomputed from xhat2
+// (reference arithmetic: autograd of timm Mlp, fc2 then GELU then fc1)
+extern "C" int rovit_gemm_mlp_bwd(const void* dY, int ldy, const void* H, int ldh, const void* W2T, const void* W1, const float* b1,
+                                  int M, void* dpre, int ldo, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(dY && H && W2T && W1 && b1 && dpre, ROVIT_ERR_NULL, "gemm_mlp_bwd: null pointer");
+  ROVIT_CHECK_ARG(M > 0, ROVIT_ERR_SHAPE, "gemm_mlp_bwd: M must be positive");
+  ROVIT_CHECK_ARG(ldy % 8 == 0 && ldh % 8 == 0 && ldo % 8 == 0 && rovit_aligned16(dY) && rovit_aligned16(H) && rovit_aligned16(W2T) &&
+                      rovit_aligned16(W1) && rovit_aligned16(b1) && rovit_aligned16(dpre),
+                  ROVIT_ERR_ALIGN, "gemm_mlp_bwd: operands must be 16-byte aligned with ld %% 8 == 0");
+  MlpBwdArgs g{(const bf16*)dY, ldy, (const bf16*)H, ldh, (const bf16*)W2T, (const bf16*)W1, b1, (bf16*)dpre, ldo, M, 4};
+  // one 12-wave workgroup per CU: 64.2 us at M = 50432; the <32, 6> form (two 6-wave workgroups per CU) needs 96 registers of
+  // weights per lane and spills at the 168-register budget of 3 waves per SIMD (102 us): not instantiated
+  return launch_mlp_bwd<64, 12>(g, (hipStream_t)stream);
+}
+
 extern "C" size_t rovit_wgrad_workspace_bytes(int N, int K, int splits) {
   return ((size_t)splits * N * K + (size_t)splits * N) * sizeof(float);
 }
 
+// Tile choice.  tile id = (TN << 16) | TK; 0 = the library's default for the shape.  Developer knob (A/B timing only):
+// rovit_set_wgrad_tile(tn, tk), environment ROVIT_WGRAD_TILE=tn,tk.
+static int g_wgrad_tile = [] {
+  const char* e = getenv("ROVIT_WGRAD_TILE");
+  int tn = 0, tk = 0;
+  if (e && sscanf(e, "%d,%d", &tn, &tk) == 2) return (tn << 16) | tk;
+  return 0;
+}();
+extern "C" int rovit_set_wgrad_tile(int tn, int tk) { g_wgrad_tile = (tn << 16) | tk; return ROVIT_OK; }
+
+static void wgrad_tile_for(int N, int K, int* tn, int* tk) {
+  int n = g_wgrad_tile >> 16, k = g_wgrad_tile & 0xffff;
+  if (n <= 0 || k <= 0 || N % n || K % k) { n = 96; k = 96; }
+  *tn = n; *tk = k;
+}
+
 extern "C" int rovit_wgrad_splits(int M, int N, int K) {
-  const int tiles = (N / WG_T) * (K / WG_T);
+  int tn, tk;
+  wgrad_tile_for(N, K, &tn, &tk);
+  const int tiles = (N / tn) * (K / tk);
   static const int target = getenv("ROVIT_WGRAD_WGS") ? atoi(getenv("ROVIT_WGRAD_WGS")) : 512;
   int s = (target + tiles - 1) / tiles;            // ~2 workgroups per CU: measured best trade against slab traffic
   s = (s + 7) / 8 * 8;
@@ -1331,11 +1559,20 @@ extern "C" int rovit_wgrad_splits(int M, int N, int K) {
   return s < 1 ? 1 : s;
 }
 
+template <int TN, int TK>
+static void launch_wgrad(const WgradArgs& g0, hipStream_t st) {
+  WgradArgs g = g0;
+  g.k_tiles = g.K / TK; g.n_tiles = g.N / TN;
+  const int nwg = g.splits * g.k_tiles * g.n_tiles;
+  if (g.patch_tokens > 0) hipLaunchKernelGGL((wgrad_kernel<TN, TK, true>), dim3(nwg), dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((wgrad_kernel<TN, TK, false>), dim3(nwg), dim3(256), 0, st, g);
+}
+
 // slab/colsum live in `ws` (rovit_wgrad_workspace_bytes); results are produced by rovit_wgrad_reduce.
 extern "C" int rovit_wgrad(const void* dY, int ldy, const void* A, int lda, int M, int N, int K, int splits, int patch_tokens,
                            float* ws, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(dY && A && ws, ROVIT_ERR_NULL, "wgrad: null pointer");
-  ROVIT_CHECK_ARG(M > 0 && N % WG_T == 0 && K % WG_T == 0 && splits > 0, ROVIT_ERR_SHAPE, "wgrad: unsupported shape N=%d K=%d", N, K);
+  ROVIT_CHECK_ARG(M > 0 && N % 96 == 0 && K % 96 == 0 && splits > 0, ROVIT_ERR_SHAPE, "wgrad: unsupported shape N=%d K=%d", N, K);
   ROVIT_CHECK_ARG(ldy % 8 == 0 && lda % 8 == 0 && rovit_aligned16(dY) && rovit_aligned16(A), ROVIT_ERR_ALIGN, "wgrad: alignment");
   WgradArgs g{};
   g.dY = (const bf16*)dY; g.ldy = ldy; g.A = (const bf16*)A; g.lda = lda; g.M = M; g.N = N; g.K = K;
@@ -1343,11 +1580,24 @@ extern "C" int rovit_wgrad(const void* dY, int ldy, const void* A, int lda, int 
   g.rows_per_split = ((M + splits - 1) / splits + WG_MSTEP - 1) / WG_MSTEP * WG_MSTEP;
   g.slab = ws; g.colsum = ws + (size_t)splits * N * K;
   g.patch_tokens = patch_tokens;
-  g.k_tiles = K / WG_T; g.n_tiles = N / WG_T; g.dbg = g_gemm_dbg >> 4;
+  g.dbg = g_gemm_dbg >> 4;
   // a split whose first row is past M still writes zeros, so the reduce can sum every slab
-  const int nwg = splits * g.k_tiles * g.n_tiles;
-  if (patch_tokens > 0) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, g);
-  else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, g);
+  int tn, tk;
+  wgrad_tile_for(N, K, &tn, &tk);
+  hipStream_t st = (hipStream_t)stream;
+  switch ((tn << 16) | tk) {
+    case (96 << 16) | 96: launch_wgrad<96, 96>(g, st); break;
+    case (64 << 16) | 96: launch_wgrad<64, 96>(g, st); break;
+    case (96 << 16) | 64: launch_wgrad<96, 64>(g, st); break;
+    case (64 << 16) | 64: launch_wgrad<64, 64>(g, st); break;
+    case (32 << 16) | 96: launch_wgrad<32, 96>(g, st); break;
+    case (96 << 16) | 32: launch_wgrad<96, 32>(g, st); break;
+    case (96 << 16) | 192: launch_wgrad<96, 192>(g, st); break;
+    case (192 << 16) | 96: launch_wgrad<192, 96>(g, st); break;
+    case (64 << 16) | 192: launch_wgrad<64, 192>(g, st); break;
+    case (192 << 16) | 64: launch_wgrad<192, 64>(g, st); break;
+    default: rovit_set_error("wgrad: no kernel for tile %d x %d", tn, tk); return ROVIT_ERR_SHAPE;
+  }
   ROVIT_CHECK_LAUNCH("wgrad_kernel");
   return ROVIT_OK;
 }

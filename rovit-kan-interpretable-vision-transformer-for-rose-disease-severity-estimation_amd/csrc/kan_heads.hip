@@ -529,8 +529,7 @@ extern "C" int rovit_kan_layer_bwd(const float* x, const float* spline_w, const 
     const int n_items = out_f * (nb + 2);
     const int threads = n_items >= 512 ? 1024 : 256;         // one or more threads per (output, basis) item
     const size_t lds = (KAN_MAX_KNOTS + (size_t)bc * (nb + 1 + out_f) + threads) * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)kan_bwd_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024); attr = true; }
+    (void)rovit_set_max_lds((const void*)kan_bwd_dw_kernel, (size_t)(104 * 1024));
     hipLaunchKernelGGL(kan_bwd_dw_kernel, dim3(in_f), dim3(threads), lds, (hipStream_t)stream, x, knots, out, grad_out,
                        d_spline_w, d_lin_w, d_lin_b, batch, in_f, out_f, n_knots, bc, act);
     ROVIT_CHECK_LAUNCH("kan_bwd_dw_kernel");

@@ -26,6 +26,15 @@ enum { B_N1W = 0, B_N1B, B_QKVW, B_QKVB, B_PROJW, B_PROJB, B_N2W, B_N2B, B_FC1W,
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// ROVIT_RECOMPUTE_GELU=1: do not store gelu'(pre) in the forward (77 MB per block at batch 256, 0.93 GB per step) and let
+// the backward recompute it from xhat2 (rovit_gemm_mlp_bwd).  Measured on MI355X at batch 256: forward fc1 51.1 -> 49.5 us
+// but backward 40.2 -> 64.2 us per block (the recompute makes the kernel VALU/phase-bound), so it is a MEMORY option,
+// not the default.
+inline bool recompute_gelu() {
+  static const bool on = [] { const char* e = getenv("ROVIT_RECOMPUTE_GELU"); return e && e[0] == '1'; }();
+  return on;
+}
+
 struct Prep {          // byte offsets into the prepared-weight buffer
   size_t wpe;
   size_t blk0, blk_stride;
@@ -79,7 +88,7 @@ struct Plan {          // byte offsets into the workspace
     xhat2 = b; b = al(b + M * D * 2);
     rstd2 = b; b = al(b + M * 4);
     act = b; b = al(b + M * MLP * 2);
-    dact = b; b = al(b + M * MLP * 2);
+    dact = b; if (!recompute_gelu()) b = al(b + M * MLP * 2);   // gelu'(pre): stored, or recomputed by the backward
     blk_stride = training ? b : 0;              // inference: every block reuses the same buffers
     blk0 = o; o += training ? (size_t)depth * b : b;
     s_qkv = rovit_wgrad_splits((int)M, 3 * D, D);
@@ -306,7 +315,7 @@ int vit_forward_impl(const float* images, const float* const* params, const void
     EACH_HALF {
       const Half& h = halves[hh];
       RUN(rovit_gemm_nt(ROWS(s + L.xhat2, D, 2), D * rs, q + P.wfc1, D, cls_only ? h.nb : h.nb * T, MLP, D, (const float*)(q + P.bfc1),
-                        EPI_GELU, ROWS(s + L.act, MLP, 2), MLP * rs, training ? ROWS(s + L.dact, MLP, 2) : nullptr, nullptr, 0, nullptr, 0,
+                        EPI_GELU, ROWS(s + L.act, MLP, 2), MLP * rs, (training && !recompute_gelu()) ? ROWS(s + L.dact, MLP, 2) : nullptr, nullptr, 0, nullptr, 0,
                         nullptr, 0, h.st));
     }
     EACH_HALF {
@@ -373,7 +382,7 @@ int vit_backward_impl(const float* d_features, const float* const* params, const
                            x0v(depth - 1), grads[P_NORM_W], grads[P_NORM_B], batch, T, stream));
   }
   // Two-stream schedule (see SideStream above).  Per block i (p = i & 1), stream A runs the dgrad chain
-  //   A1 fc2 dgrad * gelu' : x0[i%3] -> dpre[p]        A2 fc1 dgrad + norm2 bwd : dpre[p] -> dX, x1[p]
+  //   A1 fc2 dgrad * gelu' (stored, or recomputed from xhat2) : x0[i%3] -> dpre[p]        A2 fc1 dgrad + norm2 bwd : dpre[p] -> dX, x1[p]
   //   A3 proj dgrad : x1[p] -> dO                       A4 attention bwd : dO -> dqkv[p]
   //   A5 qkv dgrad + norm1 bwd : dqkv[p] -> dX, x0[(i-1)%3]
   // and stream B the weight gradients  B1 fc2 (x0[i%3], act)  B2 fc1 (dpre[p], xhat2)  B3 proj (x1[p], o)
@@ -428,8 +437,11 @@ int vit_backward_impl(const float* d_features, const float* const* params, const
       const int Mr = batch, rs = T;
       char* dp = ws + L.dpre[0];
       char* dq = ws + L.dqkv[0];
-      RUN(rovit_gemm_nt(xin, D * rs, q + P.wfc2T, D, Mr, MLP, D, nullptr, EPI_MUL, dp, MLP * rs, nullptr, nullptr, 0, s + L.dact,
-                        MLP * rs, nullptr, 0, stream));
+      if (recompute_gelu())
+        RUN(rovit_gemm_mlp_bwd(xin, D * rs, s + L.xhat2, D * rs, q + P.wfc2T, q + P.wfc1, (const float*)(q + P.bfc1), Mr, dp, MLP * rs, stream));
+      else
+        RUN(rovit_gemm_nt(xin, D * rs, q + P.wfc2T, D, Mr, MLP, D, nullptr, EPI_MUL, dp, MLP * rs, nullptr, nullptr, 0, s + L.dact,
+                          MLP * rs, nullptr, 0, stream));
       RUN(rovit_wgrad(xin, D * rs, s + L.act, MLP * rs, Mr, D, MLP, L.s_fc2c, 0, (float*)(ws + L.slab_fc2), stream));
       RUN(rovit_gemm_nt(dp, MLP * rs, q + P.wfc1T, MLP, Mr, D, MLP, nullptr, EPI_BF16, ws + L.dxhat, D * rs, nullptr, nullptr, 0, nullptr, 0,
                         nullptr, 0, stream));
@@ -452,8 +464,10 @@ int vit_backward_impl(const float* d_features, const float* const* params, const
     char* dq = ws + L.dqkv[p];
     char* xmid = ws + L.x1[p];
     if (ss && i + 2 < depth && ev_bdone[i + 2] && hipStreamWaitEvent(sA, ev_bdone[i + 2], 0) != hipSuccess) EVFAIL("event wait");
-    RUN(rovit_gemm_nt(xin, D, q + P.wfc2T, D, M, MLP, D, nullptr, EPI_MUL, dp, MLP, nullptr, nullptr, 0, s + L.dact, MLP, nullptr, 0,
-                      sA));                                                                                          // A1
+    if (recompute_gelu())                                                                                            // A1
+      RUN(rovit_gemm_mlp_bwd(xin, D, s + L.xhat2, D, q + P.wfc2T, q + P.wfc1, (const float*)(q + P.bfc1), M, dp, MLP, sA));
+    else
+      RUN(rovit_gemm_nt(xin, D, q + P.wfc2T, D, M, MLP, D, nullptr, EPI_MUL, dp, MLP, nullptr, nullptr, 0, s + L.dact, MLP, nullptr, 0, sA));
     // fc1 dgrad fused with the backward of norm2 (updates dX, writes its bf16 copy)
     RUN(rovit_gemm_ln_bwd(dp, MLP, q + P.wfc1T, MLP, M, MLP, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmid, sA));            // A2
     if (ss && !hand_over(ss, sA, sB)) EVFAIL("event hand-over");                                                   // E_i

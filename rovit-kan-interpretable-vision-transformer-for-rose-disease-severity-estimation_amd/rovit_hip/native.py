@@ -40,10 +40,12 @@ SIGNATURES = {
     'rovit_vit_backward': (_i, [_vp] * 5 + [_i] * 4 + [_vp]),
     'rovit_vit_backward_notify': (_i, [_vp] * 5 + [_i] * 4 + [_vp] + [_vp]),
     'rovit_gemm_nt': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    'rovit_gemm_mlp_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     'rovit_gemm_resid_ln': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp]),
     'rovit_gemm_ln_bwd': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'rovit_set_gemm_tile': (_i, [_i]),
     'rovit_set_gemm_debug': (_i, [_i]),
+    'rovit_set_wgrad_tile': (_i, [_i, _i]),
     'rovit_wgrad_splits': (_i, [_i, _i, _i]),
     'rovit_wgrad_workspace_bytes': (_sz, [_i, _i, _i]),
     'rovit_wgrad': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),

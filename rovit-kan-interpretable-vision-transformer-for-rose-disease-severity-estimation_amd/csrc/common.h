@@ -139,6 +139,10 @@ int rovit_layernorm_fwd_rows(const float* x, void* xhat, float* rstd, int rows, 
 int rovit_layernorm_bwd_rows(const void* dxhat, const void* xhat, const float* rstd, float* dX, void* dXb, int rows, int row_step,
                              rovit_stream_t stream);
 
+// several weight gradients G[N][K] = dY[M][N]^T A[M][K] that share M, in one launch (gemm.hip)
+struct RovitWgradDesc { const void* dY; int ldy; const void* A; int lda; int N, K; float* ws; };
+int rovit_wgrad_batch(const RovitWgradDesc* descs, int n, int M, int splits, rovit_stream_t stream);
+
 struct RovitReduceDesc {
   const float* ws; int splits, N, K;
   const float* gamma; const float* beta; const float* W;      // gamma != NULL: un-fold the LayerNorm affine

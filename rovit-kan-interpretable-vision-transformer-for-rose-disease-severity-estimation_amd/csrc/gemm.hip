@@ -1212,15 +1212,25 @@ constexpr int WG_MSTEP = 64;
 // (conflict-free ds_read_b64_tr_b16: the two 16-lane groups of a half-wave read 8 consecutive rows)
 constexpr int wg_stride(int t) { return ((t + 16) * 2 / 32) % 2 ? t + 16 : t + 32; }
 
-struct WgradArgs {
+// One weight-gradient problem G[N][K] = dY[M][N]^T A[M][K] of a launch; several problems that share M (the four linears of
+// a transformer block) run in ONE launch: with 24 output tiles per M-split instead of 2..8, the chip is filled with
+// 16-24 M-splits instead of 32-128, so the fp32 partial slabs (splits x N x K x 4 bytes, written here and read again by
+// the reduce kernel) shrink from 75.6 to 28-42 MB per block, and three launch ramps disappear.
+struct WgradProb {
   const bf16* dY; int ldy;
   const bf16* A; int lda;
-  int M, N, K;
-  int splits, rows_per_split;
+  int N, K;
   float* slab;          // [splits][N][K]
   float* colsum;        // [splits][N]
-  int patch_tokens;     // >0: dY row of m is m + m/(T-1) + 1 (skip each image's cls row)
-  int k_tiles, n_tiles;
+  int k_tiles, tile0;   // tiles of this problem are [tile0, tile0 + n_tiles * k_tiles) of a split's tile list
+};
+constexpr int WG_MAXPROB = 4;
+struct WgradArgs {
+  WgradProb p[WG_MAXPROB];
+  int nprob;
+  int M;
+  int splits, rows_per_split, tiles_per_split;
+  int patch_tokens;     // >0 (single problem only): dY row of m is m + m/(T-1) + 1 (skip each image's cls row)
   int dbg;              // developer knob: bit 0 skip steady-state global loads, bit 1 skip MFMAs
 };
 
@@ -1239,11 +1249,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   bf16* Ys = lds;                                       // [2][MSTEP][SY]
   bf16* As = lds + 2 * WG_MSTEP * SY;                   // [2][MSTEP][SA]
 
-  const int tiles = g.k_tiles * g.n_tiles;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);            // all tiles of a split on one XCD
-  const int split = bid / tiles, tile = bid - split * tiles;
+  const int split = bid / g.tiles_per_split;
+  int tile = bid - split * g.tiles_per_split;
   if (split >= g.splits) return;
-  const int ntile = tile / g.k_tiles, ktile = tile - ntile * g.k_tiles;
+  int pi = 0;
+#pragma unroll
+  for (int j = 1; j < WG_MAXPROB; ++j)
+    if (j < g.nprob && tile >= g.p[j].tile0) pi = j;
+  // (a scalar copy of the selected problem: pi is workgroup-uniform)
+  const WgradProb pr = g.p[pi];
+  tile -= pr.tile0;
+  const int ntile = tile / pr.k_tiles, ktile = tile - ntile * pr.k_tiles;
   const int n0 = ntile * TN, k0 = ktile * TK;
   const int m_begin = split * g.rows_per_split;
   const int m_end = min(g.M, m_begin + g.rows_per_split);
@@ -1263,7 +1280,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
     y_row[i] = c / CPRY;
     const int col = (c - y_row[i] * CPRY) * 8;
     y_lds[i] = y_row[i] * SY + col;
-    ybase[i] = g.dY + n0 + col;
+    ybase[i] = pr.dY + n0 + col;
   }
 #pragma unroll
   for (int i = 0; i < CHA; ++i) {
@@ -1271,7 +1288,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
     a_row[i] = c / CPRA;
     const int col = (c - a_row[i] * CPRA) * 8;
     a_lds[i] = a_row[i] * SA + col;
-    abase[i] = g.A + k0 + col;
+    abase[i] = pr.A + k0 + col;
   }
   const int m_last = g.M - 1;
   auto load = [&](int mbase, bf16x8* ry, bf16x8* ra) {
@@ -1280,13 +1297,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
       int m = mbase + y_row[i];
       m = m < m_last ? m : m_last;                      // clamp (never branch around a load); tail rows are zeroed in store()
       const int yr = PATCH ? m + m / (g.patch_tokens - 1) + 1 : m;
-      ry[i] = *(const bf16x8*)(ybase[i] + (size_t)yr * g.ldy);
+      ry[i] = *(const bf16x8*)(ybase[i] + (size_t)yr * pr.ldy);
     }
 #pragma unroll
     for (int i = 0; i < CHA; ++i) {
       int m = mbase + a_row[i];
       m = m < m_last ? m : m_last;
-      ra[i] = *(const bf16x8*)(abase[i] + (size_t)m * g.lda);
+      ra[i] = *(const bf16x8*)(abase[i] + (size_t)m * pr.lda);
     }
   };
   auto store = [&](int buf, int mbase, const bf16x8* ry, const bf16x8* ra) {
@@ -1317,7 +1334,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   for (int q = 0; q < 8; ++q) ones[q] = (bf16)1.0f;
   // bias gradient: one extra MFMA per 16 columns against a tile of ones.  The waves that hold the same dY
   // fragments (same n-tile: 2 wk x k_tiles workgroups) share the column tiles between them.
-  const int cs_owner = ktile * 2 + wk, cs_n = 2 * g.k_tiles;
+  const int cs_owner = ktile * 2 + wk, cs_n = 2 * pr.k_tiles;
   bool cs_do[JN];
 #pragma unroll
   for (int j = 0; j < JN; ++j) cs_do[j] = (j % cs_n) == cs_owner;
@@ -1372,16 +1389,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
       barrier_lds();
     }
   }
-  float* slab = g.slab + (size_t)split * g.N * g.K;
+  float* slab = pr.slab + (size_t)split * pr.N * pr.K;
 #pragma unroll
   for (int j = 0; j < JN; ++j) {
     const int n = n0 + wn * (TN / 2) + j * 16 + l15;
 #pragma unroll
     for (int i = 0; i < IK; ++i) {
       const int k = k0 + wk * (TK / 2) + i * 16 + lg * 4;
-      *(float4*)(slab + (size_t)n * g.K + k) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      *(float4*)(slab + (size_t)n * pr.K + k) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     }
-    if (cs_do[j] && lg == 0) g.colsum[(size_t)split * g.N + n] = accb[j][0];
+    if (cs_do[j] && lg == 0) pr.colsum[(size_t)split * pr.N + n] = accb[j][0];
   }
 }
 
@@ -1562,8 +1579,14 @@ extern "C" int rovit_wgrad_splits(int M, int N, int K) {
 template <int TN, int TK>
 static void launch_wgrad(const WgradArgs& g0, hipStream_t st) {
   WgradArgs g = g0;
-  g.k_tiles = g.K / TK; g.n_tiles = g.N / TN;
-  const int nwg = g.splits * g.k_tiles * g.n_tiles;
+  int t = 0;
+  for (int j = 0; j < g.nprob; ++j) {
+    g.p[j].k_tiles = g.p[j].K / TK;
+    g.p[j].tile0 = t;
+    t += (g.p[j].N / TN) * g.p[j].k_tiles;
+  }
+  g.tiles_per_split = t;
+  const int nwg = g.splits * t;
   if (g.patch_tokens > 0) hipLaunchKernelGGL((wgrad_kernel<TN, TK, true>), dim3(nwg), dim3(256), 0, st, g);
   else hipLaunchKernelGGL((wgrad_kernel<TN, TK, false>), dim3(nwg), dim3(256), 0, st, g);
 }
@@ -1575,10 +1598,11 @@ extern "C" int rovit_wgrad(const void* dY, int ldy, const void* A, int lda, int 
   ROVIT_CHECK_ARG(M > 0 && N % 96 == 0 && K % 96 == 0 && splits > 0, ROVIT_ERR_SHAPE, "wgrad: unsupported shape N=%d K=%d", N, K);
   ROVIT_CHECK_ARG(ldy % 8 == 0 && lda % 8 == 0 && rovit_aligned16(dY) && rovit_aligned16(A), ROVIT_ERR_ALIGN, "wgrad: alignment");
   WgradArgs g{};
-  g.dY = (const bf16*)dY; g.ldy = ldy; g.A = (const bf16*)A; g.lda = lda; g.M = M; g.N = N; g.K = K;
+  g.nprob = 1;
+  g.p[0] = WgradProb{(const bf16*)dY, ldy, (const bf16*)A, lda, N, K, ws, ws + (size_t)splits * N * K, 0, 0};
+  g.M = M;
   g.splits = splits;
   g.rows_per_split = ((M + splits - 1) / splits + WG_MSTEP - 1) / WG_MSTEP * WG_MSTEP;
-  g.slab = ws; g.colsum = ws + (size_t)splits * N * K;
   g.patch_tokens = patch_tokens;
   g.dbg = g_gemm_dbg >> 4;
   // a split whose first row is past M still writes zeros, so the reduce can sum every slab
@@ -1590,15 +1614,33 @@ extern "C" int rovit_wgrad(const void* dY, int ldy, const void* A, int lda, int 
     case (64 << 16) | 96: launch_wgrad<64, 96>(g, st); break;
     case (96 << 16) | 64: launch_wgrad<96, 64>(g, st); break;
     case (64 << 16) | 64: launch_wgrad<64, 64>(g, st); break;
-    case (32 << 16) | 96: launch_wgrad<32, 96>(g, st); break;
-    case (96 << 16) | 32: launch_wgrad<96, 32>(g, st); break;
     case (96 << 16) | 192: launch_wgrad<96, 192>(g, st); break;
     case (192 << 16) | 96: launch_wgrad<192, 96>(g, st); break;
-    case (64 << 16) | 192: launch_wgrad<64, 192>(g, st); break;
-    case (192 << 16) | 64: launch_wgrad<192, 64>(g, st); break;
     default: rovit_set_error("wgrad: no kernel for tile %d x %d", tn, tk); return ROVIT_ERR_SHAPE;
   }
   ROVIT_CHECK_LAUNCH("wgrad_kernel");
+  return ROVIT_OK;
+}
+
+// Several weight gradients that share M in one launch (96 x 192 tiles, `splits` M-splits for all of them); the slabs of
+// problem j live in descs[j].ws like rovit_wgrad's (rovit_wgrad_workspace_bytes(N, K, splits)).
+int rovit_wgrad_batch(const RovitWgradDesc* descs, int n, int M, int splits, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(descs && n >= 1 && n <= WG_MAXPROB && M > 0 && splits > 0, ROVIT_ERR_SHAPE, "wgrad_batch: bad arguments");
+  WgradArgs g{};
+  g.nprob = n;
+  for (int j = 0; j < n; ++j) {
+    const RovitWgradDesc& d = descs[j];
+    ROVIT_CHECK_ARG(d.dY && d.A && d.ws, ROVIT_ERR_NULL, "wgrad_batch: null pointer");
+    ROVIT_CHECK_ARG(d.N % 96 == 0 && d.K % 192 == 0, ROVIT_ERR_SHAPE, "wgrad_batch: unsupported shape N=%d K=%d", d.N, d.K);
+    ROVIT_CHECK_ARG(d.ldy % 8 == 0 && d.lda % 8 == 0 && rovit_aligned16(d.dY) && rovit_aligned16(d.A), ROVIT_ERR_ALIGN, "wgrad_batch: alignment");
+    g.p[j] = WgradProb{(const bf16*)d.dY, d.ldy, (const bf16*)d.A, d.lda, d.N, d.K, d.ws, d.ws + (size_t)splits * d.N * d.K, 0, 0};
+  }
+  g.M = M;
+  g.splits = splits;
+  g.rows_per_split = ((M + splits - 1) / splits + WG_MSTEP - 1) / WG_MSTEP * WG_MSTEP;
+  g.dbg = g_gemm_dbg >> 4;
+  launch_wgrad<96, 192>(g, (hipStream_t)stream);
+  ROVIT_CHECK_LAUNCH("wgrad_kernel (batch)");
   return ROVIT_OK;
 }
 

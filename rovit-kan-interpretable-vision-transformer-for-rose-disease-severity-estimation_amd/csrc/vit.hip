@@ -12,6 +12,7 @@
 //   attention out bf16 (M,192) + lse2 (B,3,T), act = gelu(pre) and dact = gelu'(pre) bf16 (M,768)
 //   LayerNorm affines are folded into the following Linear (W*gamma, b + W beta) by rovit_vit_prepare, so the
 //   GEMM operand is the normalised xhat itself and the wgrad recovers dgamma/dbeta from G = dY^T xhat.
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -419,11 +420,59 @@ int vit_backward_impl(const float* d_features, const float* const* params, const
          (float*)(ws + L.gscr2)}};
     return rovit_wgrad_reduce_batch(rd, 4, st);
   };
+  // Weight gradients of the two-stream schedule: ONE launch per block carries the qkv gradient of the previous block
+  // (`pending`, whose dqkv became final with its A5) together with fc2 / fc1 / proj of block i -- 24 output tiles per
+  // M-split, so S_MERGE splits fill the chip (see gemm.hip WgradProb) -- and ONE reduce launch finishes those four.
+  static const int s_merge_env = getenv("ROVIT_WGRAD_MERGE_SPLITS") ? atoi(getenv("ROVIT_WGRAD_MERGE_SPLITS")) : 16;
+  static const bool merge_env = !(getenv("ROVIT_WGRAD_MERGE") && getenv("ROVIT_WGRAD_MERGE")[0] == '0');
+  // never more splits than the slab buffers were sized for (small batches have few 64-row steps)
+  const int S_MERGE = std::min(std::min(s_merge_env, L.s_fc1), std::min(std::min(L.s_fc2, L.s_qkv), L.s_proj));
+  const bool merge = merge_env && S_MERGE >= 1;
+  auto qkv_reduce_desc = [&](int i, int splits) -> RovitReduceDesc {
+    const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
+    float* const* bg = grads + P_BLOCK0 + B_COUNT * i;
+    return {(const float*)(ws + L.slab_qkv), splits, 3 * D, D, bp[B_N1W], bp[B_N1B], bp[B_QKVW], bg[B_QKVW], bg[B_QKVB], bg[B_N1W],
+            bg[B_N1B], (float*)(ws + L.gscr2)};
+  };
   auto issue_b45 = [&](int i) -> int {                 // B4 + B5 of block i (stream B already waits for A5 of block i)
     char* s = ws + L.blk0 + (size_t)i * L.blk_stride;
-    RUN(rovit_wgrad(ws + L.dqkv[i & 1], 3 * D, s + L.xhat1, D, M, 3 * D, D, L.s_qkv, 0, (float*)(ws + L.slab_qkv), sB));
-    RUN(reduce_block(i, false, sB));
+    if (merge) {
+      // fc2 / fc1 / proj of block i were reduced with their own launch.  Same kernel, tile and split count as inside a
+      // merged launch, so a backward cut into block ranges (data-parallel buckets) stays bit-identical to an uncut one.
+      const RovitWgradDesc wd = {ws + L.dqkv[i & 1], 3 * D, s + L.xhat1, D, 3 * D, D, (float*)(ws + L.slab_qkv)};
+      RUN(rovit_wgrad_batch(&wd, 1, M, S_MERGE, sB));
+      const RovitReduceDesc rd = qkv_reduce_desc(i, S_MERGE);
+      RUN(rovit_wgrad_reduce_batch(&rd, 1, sB));
+    } else {
+      RUN(rovit_wgrad(ws + L.dqkv[i & 1], 3 * D, s + L.xhat1, D, M, 3 * D, D, L.s_qkv, 0, (float*)(ws + L.slab_qkv), sB));
+      RUN(reduce_block(i, false, sB));
+    }
     if (ss && !(ev_bdone[i] = hand_over(ss, sB, nullptr, true))) EVFAIL("event record");
+    return ROVIT_OK;
+  };
+  // merged B-stream work of one iteration: [qkv wgrad of `prev`] + fc2, fc1, proj wgrad of block i, then one reduce
+  auto issue_merged = [&](int i, int prev, const char* xin, const char* dp, const char* xmid) -> int {
+    char* s = ws + L.blk0 + (size_t)i * L.blk_stride;
+    const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
+    float* const* bg = grads + P_BLOCK0 + B_COUNT * i;
+    RovitWgradDesc wd[4];
+    RovitReduceDesc rd[4];
+    int n = 0;
+    wd[n] = {xin, D, s + L.act, MLP, D, MLP, (float*)(ws + L.slab_fc2)};
+    rd[n++] = {(const float*)(ws + L.slab_fc2), S_MERGE, D, MLP, nullptr, nullptr, nullptr, bg[B_FC2W], bg[B_FC2B], nullptr, nullptr, nullptr};
+    wd[n] = {dp, MLP, s + L.xhat2, D, MLP, D, (float*)(ws + L.slab_fc1)};
+    rd[n++] = {(const float*)(ws + L.slab_fc1), S_MERGE, MLP, D, bp[B_N2W], bp[B_N2B], bp[B_FC1W], bg[B_FC1W], bg[B_FC1B], bg[B_N2W], bg[B_N2B],
+               (float*)(ws + L.gscr)};
+    wd[n] = {xmid, D, s + L.o, D, D, D, (float*)(ws + L.slab_proj)};
+    rd[n++] = {(const float*)(ws + L.slab_proj), S_MERGE, D, D, nullptr, nullptr, nullptr, bg[B_PROJW], bg[B_PROJB], nullptr, nullptr, nullptr};
+    if (prev >= 0) {
+      char* sp = ws + L.blk0 + (size_t)prev * L.blk_stride;
+      wd[n] = {ws + L.dqkv[prev & 1], 3 * D, sp + L.xhat1, D, 3 * D, D, (float*)(ws + L.slab_qkv)};
+      rd[n++] = qkv_reduce_desc(prev, S_MERGE);
+    }
+    RUN(rovit_wgrad_batch(wd, n, M, S_MERGE, sB));
+    RUN(rovit_wgrad_reduce_batch(rd, n, sB));
+    if (prev >= 0 && ss && !(ev_bdone[prev] = hand_over(ss, sB, nullptr, true))) EVFAIL("event record");
     return ROVIT_OK;
   };
   for (int i = first_block; i >= last_block; --i) {
@@ -471,10 +520,14 @@ int vit_backward_impl(const float* d_features, const float* const* params, const
     // fc1 dgrad fused with the backward of norm2 (updates dX, writes its bf16 copy)
     RUN(rovit_gemm_ln_bwd(dp, MLP, q + P.wfc1T, MLP, M, MLP, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmid, sA));            // A2
     if (ss && !hand_over(ss, sA, sB)) EVFAIL("event hand-over");                                                   // E_i
-    if (pending >= 0) RUN(issue_b45(pending));
-    RUN(rovit_wgrad(xin, D, s + L.act, MLP, M, D, MLP, L.s_fc2, 0, (float*)(ws + L.slab_fc2), sB));                // B1
-    RUN(rovit_wgrad(dp, MLP, s + L.xhat2, D, M, MLP, D, L.s_fc1, 0, (float*)(ws + L.slab_fc1), sB));               // B2
-    RUN(rovit_wgrad(xmid, D, s + L.o, D, M, D, D, L.s_proj, 0, (float*)(ws + L.slab_proj), sB));                   // B3
+    if (merge) {
+      RUN(issue_merged(i, pending, xin, dp, xmid));                                                                // B4(prev) B1 B2 B3, B5
+    } else {
+      if (pending >= 0) RUN(issue_b45(pending));
+      RUN(rovit_wgrad(xin, D, s + L.act, MLP, M, D, MLP, L.s_fc2, 0, (float*)(ws + L.slab_fc2), sB));              // B1
+      RUN(rovit_wgrad(dp, MLP, s + L.xhat2, D, M, MLP, D, L.s_fc1, 0, (float*)(ws + L.slab_fc1), sB));             // B2
+      RUN(rovit_wgrad(xmid, D, s + L.o, D, M, D, D, L.s_proj, 0, (float*)(ws + L.slab_proj), sB));                 // B3
+    }
     RUN(rovit_gemm_nt(xmid, D, q + P.wprojT, D, M, D, D, nullptr, EPI_BF16, ws + L.dO, D, nullptr, nullptr, 0, nullptr, 0, nullptr, 0,
                       sA));                                                                                          // A3
     RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, dq, batch, T, H, D / H, 0.125f, sA));       // A4

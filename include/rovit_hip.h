@@ -57,6 +57,18 @@ int rovit_kan_layer_fwd(const float* x, const float* spline_w, const float* knot
 int rovit_kan_layer_bwd(const float* x, const float* spline_w, const float* knots, const float* lin_w, const float* out,
                         const float* grad_out, float* dx, float* d_spline_w, float* d_lin_w, float* d_lin_b, int batch,
                         int in_f, int out_f, int n_knots, int act, int accumulate_dx, rovit_stream_t stream);
+/* Prepared weight layouts of one KAN layer for rovit_kan_stack_fwd (re-run whenever the parameters change):
+ * spline_w (in, out, nb) -> spline_wt (in, nb, out); lin_w (out, in) -> lin_wt (in, out). */
+int rovit_kan_prepare(const float* spline_w, const float* lin_w, float* spline_wt, float* lin_wt, int in_f, int out_f, int n_basis,
+                      rovit_stream_t stream);
+/* KANSeverityModule.forward (models/kan.py:138-149) in ONE launch: every layer with its activation; the activations
+ * stay on the CU between layers.  spline_wt / knots / lin_wt / lin_b / outs are HOST arrays of n_layers device pointers
+ * (spline_wt, lin_wt: the prepared layouts above), dims the n_layers + 1 widths (widths after the input <= 64), acts the
+ * ROVIT_ACT_* after each layer.  outs[l] (batch, dims[l+1]) receives layer l's post-activation output: the last is the
+ * module output, the others are what rovit_kan_layer_bwd and get_activation_trajectory (:154-167) need. */
+int rovit_kan_stack_fwd(const float* x, const float* const* spline_wt, const float* const* knots, const float* const* lin_wt,
+                        const float* const* lin_b, float* const* outs, int batch, const int* dims, const int* n_knots,
+                        const int* acts, int n_layers, rovit_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * MLP heads.  rovit_linear_* are the building block (nn.Linear [+ReLU] [*dropout mask] [clamp +-10]);

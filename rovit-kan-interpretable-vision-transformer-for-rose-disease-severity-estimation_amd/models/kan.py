@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from rovit_hip import native
-from rovit_hip.functions import ACT_NONE, ACT_RELU, ACT_SIGMOID3, KANLayerFn
+from rovit_hip.functions import ACT_NONE, ACT_RELU, ACT_SIGMOID3, KANLayerFn, KANStackFn
 
 
 def _check_degree(degree: int):
@@ -63,12 +63,48 @@ class KANSeverityModule(nn.Module):
         self.layers_dims, self.num_knots, self.degree = layers, num_knots, degree
         self.kan_layers = nn.ModuleList(KANLayer(a, b, num_knots, degree) for a, b in zip(layers[:-1], layers[1:]))
         self.activations = nn.ModuleList(nn.ReLU() for _ in range(len(layers) - 2))
+        self.fused_min_batch = 2048
+
+    def _fusable(self) -> bool:
+        """rovit_kan_stack_fwd: up to 4 layers, widths after the input <= 64 and a multiple of 4 (or < 8)."""
+        d = self.layers_dims
+        return (1 <= len(self.kan_layers) <= 4 and all(w <= 64 and (w % 4 == 0 or w < 8) for w in d[1:]) and
+                all(l.knots.numel() <= 64 for l in self.kan_layers))
+
+    def _prepared(self):
+        """Per layer (spline_wt (in, nb, out), lin_wt (in, out)): the layouts rovit_kan_stack_fwd reads, rebuilt (one tiny
+        launch per layer) whenever a parameter changed -- torch bumps ``_version`` on in-place updates; optimizers that
+        write through flat buffers (RoViTAdamW) call ``invalidate_prepared()``."""
+        key = tuple((p.data_ptr(), p._version) for l in self.kan_layers for p in (l.spline_weights, l.linear.weight))
+        if key != getattr(self, '_prep_key', None) or self._prep[0][0].device != self.kan_layers[0].spline_weights.device:
+            prep = []
+            for l in self.kan_layers:
+                w, lw = l.spline_weights.detach().float().contiguous(), l.linear.weight.detach().float().contiguous()
+                wt = torch.empty(l.in_features, l.num_basis, l.out_features, device=w.device, dtype=torch.float32)
+                lwt = torch.empty(l.in_features, l.out_features, device=w.device, dtype=torch.float32)
+                native.call('rovit_kan_prepare', native.ptr(w), native.ptr(lw), native.ptr(wt), native.ptr(lwt), l.in_features,
+                            l.out_features, l.num_basis, native.stream_ptr())
+                prep.append((wt, lwt))
+            self._prep, self._prep_key = prep, key
+        return self._prep
+
+    def invalidate_prepared(self):
+        self._prep_key = None
 
     def _trajectory(self, x: torch.Tensor) -> List[torch.Tensor]:
-        acts = [x]
         last = len(self.kan_layers) - 1
+        codes = tuple(ACT_SIGMOID3 if i == last else ACT_RELU for i in range(last + 1))
+        # One launch with the activations on the CU pays off when there are enough samples to fill the chip with sample
+        # tiles (measured on MI355X, kernels only: batch 65536 4.4x / 11x faster than the per-layer kernels at G = 5 / 32;
+        # batch 256-512 2-4x SLOWER: a tile walks its 192 input features serially, the per-layer kernels split them)
+        if self._fusable() and x.shape[0] >= self.fused_min_batch:
+            flat = []
+            for layer in self.kan_layers:
+                flat += [layer.spline_weights, layer.knots, layer.linear.weight, layer.linear.bias]
+            return [x, *KANStackFn.apply(x, codes, self._prepared(), *flat)]
+        acts = [x]
         for i, layer in enumerate(self.kan_layers):      # activation fused into the layer kernel
-            x = layer._run(x, ACT_SIGMOID3 if i == last else ACT_RELU)
+            x = layer._run(x, codes[i])
             acts.append(x)
         return acts
 

@@ -54,6 +54,59 @@ class KANLayerFn(torch.autograd.Function):
         return dx, dws, None, dlw, dlb, None
 
 
+class KANStackFn(torch.autograd.Function):
+    """KANSeverityModule.forward (reference models/kan.py:138-149) as ONE launch (rovit_kan_stack_fwd); backward runs the
+    per-layer kernels in reverse on the activations the fused forward wrote.
+    inputs: x, acts (tuple of ROVIT_ACT_*), prep (list of per-layer (spline_wt, lin_wt) prepared tensors), then per layer
+    (spline_w, knots, lin_w, lin_b); outputs: every layer's output."""
+
+    @staticmethod
+    def forward(ctx, x, acts, prep, *params):
+        import ctypes as C
+        x = _f32c(x)
+        params = [_f32c(p) for p in params]
+        n = len(params) // 4
+        B = x.shape[0]
+        dims = [x.shape[1]] + [params[4 * l + 2].shape[0] for l in range(n)]
+        nks = [params[4 * l + 1].numel() for l in range(n)]
+        outs = [torch.empty(B, dims[l + 1], device=x.device, dtype=torch.float32) for l in range(n)]
+        arr = lambda xs: (C.c_int * len(xs))(*xs)
+        call('rovit_kan_stack_fwd', ptr(x), ptr_array([p[0] for p in prep]), ptr_array(params[1::4]), ptr_array([p[1] for p in prep]),
+             ptr_array(params[3::4]), ptr_array(outs), B, arr(dims), arr(nks), arr(list(acts)), n, stream_ptr())
+        ctx.save_for_backward(x, *params, *outs)
+        ctx.n, ctx.acts = n, tuple(acts)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        x, params, outs = saved[0], saved[1:1 + 4 * n], saved[1 + 4 * n:]
+        st = stream_ptr()
+        grads = [None] * (4 * n)
+        g = None                                         # dL/d(output of layer l), accumulated from above and from gouts[l]
+        for l in range(n - 1, -1, -1):
+            go = gouts[l]
+            if go is not None:
+                go = _f32c(go)
+                g = go if g is None else g + go
+            if g is None:
+                continue
+            w, knots, lw = params[4 * l], params[4 * l + 1], params[4 * l + 2]
+            xin = x if l == 0 else outs[l - 1]
+            need_dx = l > 0 or ctx.needs_input_grad[0]
+            need_dw = any(ctx.needs_input_grad[3 + 4 * l + k] for k in (0, 2, 3))
+            dx = torch.empty_like(xin) if need_dx else None
+            dws = torch.empty_like(w) if need_dw else None
+            dlw = torch.empty_like(lw) if need_dw else None
+            dlb = torch.empty(lw.shape[0], device=x.device, dtype=torch.float32) if need_dw else None
+            call('rovit_kan_layer_bwd', ptr(xin), ptr(w), ptr(knots), ptr(lw), ptr(outs[l]), ptr(g), ptr(dx), ptr(dws), ptr(dlw),
+                 ptr(dlb), xin.shape[0], xin.shape[1], lw.shape[0], knots.numel(), ctx.acts[l], 0, st)
+            grads[4 * l], grads[4 * l + 2], grads[4 * l + 3] = dws, dlw, dlb
+            g = dx
+        return (g if ctx.needs_input_grad[0] else None, None, None, *grads)
+
+
 # ------------------------------------------------------------------------------------------------
 # The three MLP heads (reference: models/heads.py:17-22, 38-43, 91-102; gate: models/rovit_kan.py:93-116)
 # ------------------------------------------------------------------------------------------------

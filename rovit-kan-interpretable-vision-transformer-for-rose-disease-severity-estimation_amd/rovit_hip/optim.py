@@ -156,6 +156,8 @@ class RoViTAdamW(torch.optim.Optimizer):
                  self.p_flat.numel(), coef, float(gb['lr']), gb['betas'][0], gb['betas'][1], gb['eps'], gb['weight_decay'], self.t, sp)
             eng._prep_key = None            # parameters changed behind torch's version counters: re-prepare weights
         # consecutive active segments with the same step count share one launch (the usual case: all of them)
+        if active and hasattr(self.model, 'kan_module') and hasattr(self.model.kan_module, 'invalidate_prepared'):
+            self.model.kan_module.invalidate_prepared()      # parameters change behind torch's version counters
         for first, last in self._runs(active, same_t=True):
             n = last.offset + last.numel - first.offset
             for s in active[active.index(first):active.index(last) + 1]:

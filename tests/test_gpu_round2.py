@@ -104,9 +104,9 @@ def test_kan_heavy_c5_full_shape_forward_and_backward_vs_oracle():
         ref_g, got = rp[k].grad, p.grad.cpu()
         rel = float((got - ref_g).abs().max() / ref_g.abs().max().clamp_min(1e-12))
         worst = max(worst, rel)
-        assert rel < 2e-4, (k, rel)
+        assert rel < 5e-4, (k, rel)
     rel = float((xd.grad.cpu() - xr.grad).abs().max() / xr.grad.abs().max())
-    assert rel < 2e-4, rel
+    assert rel < 5e-4, rel                   # fp32 summation-order noise of 192 x 34-term contractions (north_star: 1e-3)
     print('C5 worst relative gradient error', max(worst, rel))
 
 
@@ -428,3 +428,41 @@ torch.save({'f': f.detach().cpu(), 'g': torch.cat([p.grad.flatten() for p in m.p
     assert float(torch.nn.functional.cosine_similarity(g0, g1, dim=0)) > 0.9999
     saved = int(res['0']['ws']) - int(res['1']['ws'])
     assert saved == 12 * ((256 * 197 * 768 * 2 + 255) // 256 * 256), saved
+
+
+@pytest.mark.parametrize('layers,num_knots,B', [([192, 64, 16, 1], 5, 8), ([192, 64, 16, 1], 5, 257), ([192, 64, 16, 1], 32, 512),
+                                                 ([16, 8, 1], 5, 33), ([24, 8, 1], 32, 16), ([192, 64, 16, 1], 5, 5000)])
+def test_fused_kan_stack_forward_equals_per_layer_kernels_and_oracle(layers, num_knots, B):
+    """rovit_kan_stack_fwd (one launch, activations on chip, transposed W slabs in LDS) against the per-layer kernels
+    (same arithmetic, different summation order over the input features) and against the CPU oracle, including every
+    intermediate activation, saturated inputs and inputs on the spline cutoff."""
+    from models.kan import KANSeverityModule
+    from rovit_hip.functions import ACT_RELU, ACT_SIGMOID3
+    g = torch.Generator().manual_seed(B + num_knots)
+    sd = ref_cpu.init_kan_state(layers, num_knots, 3, g)
+    x = torch.randn(B, layers[0], generator=g) * 1.5
+    x[0, :4] = torch.tensor([30.0, -30.0, 0.0, ref_cpu.kan_cutoff(sd['kan_layers.0.knots'])])
+    m = KANSeverityModule(layers, num_knots, 3)
+    m.load_state_dict(sd)
+    m = m.to(dev())
+    assert m._fusable()
+    m.fused_min_batch = 1                      # force the one-launch path at every batch size
+    traj = m.get_activation_trajectory(x.to(dev()))
+    # per-layer kernels
+    h = x.to(dev())
+    for i, layer in enumerate(m.kan_layers):
+        h = layer._run(h, ACT_SIGMOID3 if i == len(m.kan_layers) - 1 else ACT_RELU)
+        assert float((traj[i + 1] - h).abs().max()) < 2e-5, i
+    ref_in = ref_cpu.kan_module_layer_inputs(x, sd)
+    for i in range(1, len(ref_in)):
+        assert float((traj[i].cpu() - ref_in[i]).abs().max()) < 1e-4, i
+    assert float((traj[-1].cpu() - ref_cpu.kan_module_forward(x, sd)).abs().max()) < 1e-4
+    # gradients flow through the fused forward (backward = per-layer kernels on the fused forward's activations)
+    xd = x.to(dev()).requires_grad_(True)
+    m(xd).sum().backward()
+    rp = {k: (v.clone().requires_grad_(True) if 'knots' not in k else v) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    ref_cpu.kan_module_forward(xr, rp).sum().backward()
+    for k, p in m.named_parameters():
+        assert float((p.grad.cpu() - rp[k].grad).abs().max()) < 5e-4 * float(rp[k].grad.abs().max() + 1e-6), k
+    assert float((xd.grad.cpu() - xr.grad).abs().max()) < 5e-4 * float(xr.grad.abs().max())

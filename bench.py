@@ -38,51 +38,77 @@ def build_optimizer(model, lr=1e-4, wd=1e-4):
     return torch.optim.AdamW([{'params': bb, 'lr': lr / 10}, {'params': hd, 'lr': lr}], weight_decay=wd)
 
 
-def _event_avg_ms(dev, run, iters):
+def _event_avg_ms(dev, run, iters, per_launch=True):
+    """Average duration of one call of `run` from device events on the stream it launches on.  per_launch=True brackets
+    EVERY launch with its own pair of events (a kernel's whole life, first workgroup in to last workgroup out -- what
+    rocprofv3 --kernel-trace reports per dispatch); per_launch=False times the back-to-back train, where one launch's
+    ramp hides in the previous launch's tail (throughput view; 10-18 % shorter for these 20-100 us kernels)."""
     for _ in range(5):
         run()
     st = torch.cuda.current_stream(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    for _ in range(iters):
+    if not per_launch:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(iters):
+            run()
+        e1.record(st)
+        e1.synchronize()
+        return e0.elapsed_time(e1) / iters
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record(st)
         run()
-    e1.record(st)
-    e1.synchronize()
-    return e0.elapsed_time(e1) / iters
+        b.record(st)
+    evs[-1][1].synchronize()
+    return sum(a.elapsed_time(b) for a, b in evs) / iters
+
+
+def _pmc_traffic(kernel_key):
+    """HBM bytes per launch measured with rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 2x read
+    correction) for `python bench.py --roofline-only`: read from the tracked profiles/r02_pmc_traffic.json, or None."""
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel_key, {}).get('traffic_bytes')
+    except (OSError, ValueError):
+        return None
 
 
 def wgrad_roofline(dev, iters=30):
-    """Dominant kernel of the step: wgrad_kernel<false> (48 launches, ~18 % of the kernel time; rocprofv3 summary in
-    profiles/).  Timed here at its largest shape, the fc1 weight gradient G(768,192) = dPre(M,768)^T xhat(M,192) with
-    M = 50432 (the fc2 shape moves the same bytes), from device events on the stream it is launched on.  It is
-    HBM-bound (32 FLOP per byte read): achieved = algorithmic bytes / duration against the HBM peak."""
+    """Dominant kernel of the step (rocprofv3 summaries in profiles/): wgrad_kernel<96,192,false>, the ONE weight-gradient
+    launch per transformer block: G = dY^T A for the qkv, fc2, fc1 and proj linears together (M = 50432 rows, 24 output
+    tiles of 96 x 192 per M-split, 16 splits).  Timed from device events on the stream it is launched on.  HBM-bound
+    (<= 48 FLOP per byte read): achieved = algorithmic bytes / duration against the HBM peak."""
+    import ctypes as C
     from rovit_hip import native
     lib = native.load()
-    M, N, K = 256 * 197, 768, 192
-    dY = torch.randn(M, N, device=dev).to(torch.bfloat16)
-    X = torch.randn(M, K, device=dev).to(torch.bfloat16)
-    splits = lib.rovit_wgrad_splits(M, N, K)
-    slab = torch.empty(lib.rovit_wgrad_workspace_bytes(N, K, splits), dtype=torch.uint8, device=dev)
+    M, splits = 256 * 197, 16
+    shapes = [(576, 192), (192, 768), (768, 192), (192, 192)]       # (N, K) of qkv, fc2, fc1, proj
+    dY = [torch.randn(M, n, device=dev).to(torch.bfloat16) for n, _ in shapes]
+    A = [torch.randn(M, k, device=dev).to(torch.bfloat16) for _, k in shapes]
+    ws = [torch.empty(lib.rovit_wgrad_workspace_bytes(n, k, splits), dtype=torch.uint8, device=dev) for n, k in shapes]
+    arr = lambda xs: (C.c_int * len(xs))(*xs)
+    a_dy, a_a, a_ws = native.ptr_array(dY), native.ptr_array(A), native.ptr_array(ws)
+    ldy, lda, Ns, Ks = arr([n for n, _ in shapes]), arr([k for _, k in shapes]), arr([n for n, _ in shapes]), arr([k for _, k in shapes])
 
     def run():
-        native.call('rovit_wgrad', native.ptr(dY), N, native.ptr(X), K, M, N, K, splits, 0, native.ptr(slab), native.stream_ptr())
+        native.call('rovit_wgrad_multi', a_dy, ldy, a_a, lda, Ns, Ks, a_ws, 4, M, splits, native.stream_ptr())
     ms = _event_avg_ms(dev, run, iters)
-    flops = 2.0 * M * N * K
-    # algorithmic bytes per launch (DESIGN.md section 4): read dPre (M*N) and xhat (M*K) in bf16, write G (N*K) in fp32
-    alg_bytes = 2.0 * (M * N + M * K) + 4.0 * N * K
+    ms_train = _event_avg_ms(dev, run, iters, per_launch=False)
+    flops = sum(2.0 * M * n * k for n, k in shapes)
+    # algorithmic bytes per launch (DESIGN.md section 4): read dY (M*N) and A (M*K) in bf16, write G (N*K) in fp32, per problem
+    alg_bytes = sum(2.0 * M * (n + k) + 4.0 * n * k for n, k in shapes)
     gbs = alg_bytes / (ms * 1e-3) / 1e9
-    return {'bound': 'hbm', 'kernel': f'wgrad_kernel<false>: fc1 weight gradient, M=50432 N=768 K=192, {splits} M-splits (32 FLOP/B, below the ridge)',
+    return {'bound': 'hbm', 'kernel': f'wgrad_kernel<96,192,false>: weight gradients of one block (qkv+fc2+fc1+proj) in one launch, M=50432, {splits} M-splits',
             'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
-            'avg_us': round(ms * 1e3, 2), 'algorithmic_bytes': alg_bytes,
-            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 2x read correction: profiles/r01_pmc_traffic.txt
-            # (includes the fp32 partial-sum slabs the split-M reduction writes: 18.9 MB)
-            'traffic': 127.33e6,
+            'avg_us': round(ms * 1e3, 2), 'avg_us_back_to_back': round(ms_train * 1e3, 2), 'algorithmic_bytes': alg_bytes,
+            'traffic': _pmc_traffic('wgrad_kernel<96,192,false>'),
             'mfma_tflops': round(flops / (ms * 1e-3) / 1e12, 1)}
 
 
 def gemm_roofline(dev, iters=30):
-    """Second kernel of the step by time (fc1 forward: M=50432, N=768, K=192, GELU + GELU' epilogue; the largest
-    single launch), same method."""
+    """Second kernel class of the step (fc1 forward: M=50432, N=768, K=192, GELU + GELU' epilogue; the largest single
+    GEMM launch), same method."""
     from rovit_hip import native
     M, N, K = 256 * 197, 768, 192
     A = torch.randn(M, K, device=dev).to(torch.bfloat16)
@@ -99,37 +125,130 @@ def gemm_roofline(dev, iters=30):
     # algorithmic bytes per launch: read xhat (M*K) + W (N*K), write act + dact (2*M*N), all bf16
     alg_bytes = 2.0 * (M * K + N * K + 2 * M * N)
     gbs = alg_bytes / (ms * 1e-3) / 1e9
-    return {'bound': 'hbm', 'kernel': 'gemm_ws_dma_kernel<GELU>: fc1 forward, M=50432 N=768 K=192 (85 FLOP/B, below the ridge)',
+    return {'bound': 'hbm', 'kernel': 'gemm_ws_dma_kernel<1>: fc1 forward + GELU, M=50432 N=768 K=192 (85 FLOP/B, below the ridge)',
             'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
             'avg_us': round(ms * 1e3, 2), 'algorithmic_bytes': alg_bytes,
-            'traffic': None,
+            'traffic': _pmc_traffic('gemm_ws_dma_kernel<1>'),
             'mfma_tflops': round(flops / (ms * 1e-3) / 1e12, 1), 'mfma_frac_of_dense_bf16_peak': round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """The CPU oracle (port of the reference algorithm; the reference itself needs timm and cannot run here) on a
-    bounded sample of the same workload: fwd + loss + bwd of the full model, fp32, all host cores."""
+def kan_roofline(dev, iters=30):
+    """KAN spline head (north_star: HBM roofline, no MFMA), kernels only (direct C-ABI calls):
+    C5 = BASELINE.json configs[4] (num_knots 32, batch 512: three per-layer launches, the faster path at that size) and
+    the streaming shape batch 65536 (one fused launch, rovit_kan_stack_fwd).  Algorithmic bytes: the
+    weights once per launch + x and every layer output once."""
+    import ctypes as C
+    from models.kan import KANSeverityModule
+    from rovit_hip import native
+    from rovit_hip.functions import ACT_RELU, ACT_SIGMOID3
+    from rovit_hip.native import ptr, ptr_array
+    lib = native.load()
+    layers = [192, 64, 16, 1]
+    res = {}
+    for key, G, B in (('c5_g32_b512', 32, 512), ('stream_g5_b65536', 5, 65536), ('c3_g5_b256', 5, 256)):
+        m = KANSeverityModule(layers, G, 3).to(dev)
+        nb, n = G + 2, 3
+        x = torch.randn(B, 192, device=dev)
+        outs = [torch.empty(B, layers[l + 1], device=dev) for l in range(n)]
+        arr = lambda xs: (C.c_int * len(xs))(*xs)
+        sp = native.stream_ptr()
+        fused = B >= m.fused_min_batch
+        if fused:
+            prep = m._prepared()
+            args = (ptr(x), ptr_array([p[0] for p in prep]), ptr_array([l.knots for l in m.kan_layers]), ptr_array([p[1] for p in prep]),
+                    ptr_array([l.linear.bias for l in m.kan_layers]), ptr_array(outs), B, arr(layers),
+                    arr([l.knots.numel() for l in m.kan_layers]), arr([ACT_RELU, ACT_RELU, ACT_SIGMOID3]), n, sp)
+            run = lambda: lib.rovit_kan_stack_fwd(*args)
+        else:
+            ins = [x] + outs[:-1]
+            raw = [(ptr(ins[i]), ptr(l.spline_weights), ptr(l.knots), ptr(l.linear.weight), ptr(l.linear.bias), ptr(outs[i]), B, l.in_features,
+                    l.out_features, l.knots.numel(), ACT_SIGMOID3 if i == n - 1 else ACT_RELU, sp) for i, l in enumerate(m.kan_layers)]
+
+            def run():
+                for r in raw:
+                    lib.rovit_kan_layer_fwd(*r)
+        ms = _event_avg_ms(dev, run, iters)
+        w_bytes = sum(a * b * nb + a * b + b for a, b in zip(layers[:-1], layers[1:])) * 4
+        act_bytes = B * (layers[0] + (sum(layers[1:]) if fused else 2 * sum(layers[1:-1]) + layers[-1])) * 4
+        alg = float(w_bytes + act_bytes)
+        gbs = alg / (ms * 1e-3) / 1e9
+        res[key] = {'bound': 'hbm', 'kernel': 'kan_stack_fwd_kernel (one launch)' if fused else 'kan_fwd_kernel x3 (per layer)',
+                    'num_knots': G, 'batch': B, 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(gbs / HBM_PEAK_GBS, 5), 'avg_us': round(ms * 1e3, 2), 'algorithmic_bytes': alg, 'traffic': None}
+    return res
+
+
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline():
+    """The CPU oracle (a port of the reference's algorithm; the reference itself needs timm and never travels to this
+    box) on BOUNDED samples of the same workload, fp32, on this box's host cores -- BASELINE.md section 3's plan:
+    backbone fwd and fwd+bwd at batch 256, the KAN head vectorised AND loop-faithful (what the reference's Python
+    really does, models/kan.py:85-89), the full training step, and the reference's own fps() protocol
+    (evaluation/metrics.py:63-93: batch 1, warm-up then timed forwards).  About 40 s in all."""
     from oracle import ref_cpu
-    cores = min(len(os.sched_getaffinity(0)), 32)      # the box's CPU share, not the host's 256 hardware threads
+    cores = min(len(os.sched_getaffinity(0)), 32)      # the box's CPU share, not the host's hardware threads
     torch.set_num_threads(cores)
     sd = ref_cpu.init_rovit_state(seed=0)
+    out = {'cores': cores, 'cpu_model': _cpu_model(), 'kind': 'port', 'unit': 'images/sec'}
+
+    def timed(fn, budget, max_n):
+        fn()
+        t0, n = time.time(), 0
+        while n < max_n and (n == 0 or time.time() - t0 < budget):
+            fn()
+            n += 1
+        return n, time.time() - t0
+
+    # full training step (the quantity `value` is): fwd + loss + bwd, batch 16
     params = {k: (v.clone().requires_grad_(True) if 'knots' not in k else v) for k, v in sd.items()}
     B = 16
     x = torch.randn(B, 3, 224, 224)
     y = torch.randint(0, 4, (B,))
 
     def step():
-        out = ref_cpu.rovit_forward(x, params, 4)
-        ref_cpu.joint_loss(out, y, y, 4)['total_loss'].backward()
-    step()
-    t0 = time.time()
-    n = 0
-    while time.time() - t0 < seconds_budget and n < 20:
-        step()
-        n += 1
-    dt = time.time() - t0
-    return {'value': round(n * B / dt, 2), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'{n} steps of batch {B}, fwd+loss+bwd, fp32, vectorised KAN restatement (oracle/ref_cpu.py)'}
+        ref_cpu.joint_loss(ref_cpu.rovit_forward(x, params, 4), y, y, 4)['total_loss'].backward()
+    n, dt = timed(step, 8.0, 20)
+    out['value'] = round(n * B / dt, 2)
+    out['sample'] = f'{n} training steps (fwd+loss+bwd) of batch {B}, vectorised KAN restatement (oracle/ref_cpu.py)'
+    # backbone alone at batch 256 (BASELINE.json configs[1])
+    xb = torch.randn(256, 3, 224, 224)
+    with torch.no_grad():
+        n, dt = timed(lambda: ref_cpu.vit_forward(xb, sd, prefix='backbone.model.'), 4.0, 3)
+    out['backbone_fwd_b256'] = round(n * 256 / dt, 1)
+    bp = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith('backbone.')}
+    n, dt = timed(lambda: ref_cpu.vit_forward(xb, bp, prefix='backbone.model.').square().mean().backward(), 6.0, 2)
+    out['backbone_fwd_bwd_b256'] = round(n * 256 / dt, 1)
+    # KAN head, features (256,192): vectorised einsum restatement and the reference's in x out Python loop
+    f = torch.randn(256, 192)
+    with torch.no_grad():
+        n, dt = timed(lambda: ref_cpu.kan_module_forward(f, sd, 'kan_module.'), 1.0, 50)
+        out['kan_fwd_b256_vectorised_ms'] = round(dt / n * 1e3, 2)
+        n, dt = timed(lambda: ref_cpu.kan_module_forward(f, sd, 'kan_module.', loop=True), 4.0, 2)
+        out['kan_fwd_b256_loop_faithful_ms'] = round(dt / n * 1e3, 1)
+        # the reference's fps() protocol (batch 1; bounded: 1 warm-up + up to 4 timed instead of 10 + 100), KAN active
+        x1 = torch.randn(1, 3, 224, 224)
+
+        def one():
+            feats = ref_cpu.vit_forward(x1, sd, prefix='backbone.model.')
+            o = ref_cpu.heads_forward(feats, sd, 4)
+            o['kan_severity'] = ref_cpu.kan_module_forward(feats, sd, 'kan_module.', loop=True)
+        n, dt = timed(one, 6.0, 4)
+        out['fps_protocol_batch1_kan_loop'] = round(n / dt, 2)
+        n, dt = timed(lambda: ref_cpu.rovit_forward(x1, sd, 4), 2.0, 30)
+        out['fps_protocol_batch1_kan_vectorised'] = round(n / dt, 2)
+    out['note'] = ('reference publishes 2.6 img/s (KAN active) / 36.7 img/s (backbone + cls head) for its fps() protocol on an '
+                   'unnamed CPU (README.md:315,340)')
+    return out
 
 
 def main():
@@ -141,11 +260,11 @@ def main():
     ap.add_argument('--buckets', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--roofline-only', action='store_true',
-                    help='run only the two roofline kernel measurements (the command profiles/r01_roofline_kernel_stats.csv is taken from)')
+                    help='run only the roofline kernel measurements (the command profiles/r02_roofline_kernel_stats.csv and the PMC passes are taken from)')
     args = ap.parse_args()
     if args.roofline_only:
         dev = torch.device('cuda:0')
-        print(json.dumps({'roofline': wgrad_roofline(dev), 'roofline_gemm': gemm_roofline(dev)}), flush=True)
+        print(json.dumps({'roofline': wgrad_roofline(dev), 'roofline_gemm': gemm_roofline(dev), 'roofline_kan': kan_roofline(dev)}), flush=True)
         return
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -154,7 +273,11 @@ def main():
     force_dist = os.environ.get('ROVIT_FORCE_DIST') == '1'      # exercise the RCCL code path on a single GPU
     if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29511')
+        if 'MASTER_PORT' not in os.environ:                  # single-process RCCL check: any free port
+            import socket
+            with socket.socket() as so:
+                so.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(so.getsockname()[1])
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         torch.cuda.set_device(local)
@@ -216,11 +339,13 @@ def main():
                                    '224x224x3 randn images, random-init weights' % args.batch,
                        'step': 'fwd + JointLoss + bwd + grad all-reduce + clip_grad_norm(1.0) + AdamW',
                        'global_batch': world * args.batch, 'parallelism': f'dp{world}', 'grad_buckets': args.buckets,
+                       'rccl_world': dist.get_world_size() if dist.is_initialized() else 0,
                        'backbone_mfma_frac_of_step': round(ips / world * TRAIN_FLOP_PER_IMG / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
             'final_loss': round(final_loss, 5),
         }
         res['roofline'] = wgrad_roofline(dev)
         res['roofline_gemm'] = gemm_roofline(dev)
+        res['roofline_kan'] = kan_roofline(dev)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res), flush=True)

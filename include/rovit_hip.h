@@ -167,6 +167,12 @@ int rovit_wgrad_splits(int M, int N, int K);
 size_t rovit_wgrad_workspace_bytes(int N, int K, int splits);
 int rovit_wgrad(const void* dY, int ldy, const void* A, int lda, int M, int N, int K, int splits, int patch_tokens, float* ws,
                 rovit_stream_t stream);
+/* Up to 4 weight gradients that share M (the four linears of a transformer block) in ONE launch: 96 x 192 output tiles,
+ * `splits` M-splits for all of them (24 tiles per split for a DeiT-Tiny block, so 16 splits fill the chip and the fp32
+ * partial slabs are 28 MB instead of 75.6 MB per block).  Arrays of n entries; ws[j] sized by
+ * rovit_wgrad_workspace_bytes(N[j], K[j], splits) and finished by rovit_wgrad_reduce with the same `splits`. */
+int rovit_wgrad_multi(const void* const* dY, const int* ldy, const void* const* A, const int* lda, const int* N, const int* K,
+                      float* const* ws, int n, int M, int splits, rovit_stream_t stream);
 int rovit_wgrad_reduce(const float* ws, int splits, int N, int K, const float* gamma, const float* beta, const float* W,
                        float* dW, float* db, float* dgamma, float* dbeta, float* g_scratch, rovit_stream_t stream);
 /* softmax(q k^T * scale) v per (image, head); qkv bf16 (B*T, 3*H*64) = [q|k|v]; out bf16 (B*T, H*64);

@@ -1644,6 +1644,16 @@ int rovit_wgrad_batch(const RovitWgradDesc* descs, int n, int M, int splits, rov
   return ROVIT_OK;
 }
 
+// C-ABI form of rovit_wgrad_batch: up to 4 weight gradients that share M in one launch (the per-block launch of
+// rovit_vit_backward); arrays of n entries.  ws[j] as for rovit_wgrad with the same `splits`.
+extern "C" int rovit_wgrad_multi(const void* const* dY, const int* ldy, const void* const* A, const int* lda, const int* N, const int* K,
+                                 float* const* ws, int n, int M, int splits, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(dY && ldy && A && lda && N && K && ws && n >= 1 && n <= WG_MAXPROB, ROVIT_ERR_NULL, "wgrad_multi: bad arguments");
+  RovitWgradDesc d[WG_MAXPROB];
+  for (int j = 0; j < n; ++j) d[j] = {dY[j], ldy[j], A[j], lda[j], N[j], K[j], ws[j]};
+  return rovit_wgrad_batch(d, n, M, splits, stream);
+}
+
 extern "C" int rovit_wgrad_reduce(const float* ws, int splits, int N, int K, const float* gamma, const float* beta,
                                   const float* W, float* dW, float* db, float* dgamma, float* dbeta, float* g_scratch,
                                   rovit_stream_t stream) {

@@ -51,6 +51,7 @@ SIGNATURES = {
     'rovit_wgrad_splits': (_i, [_i, _i, _i]),
     'rovit_wgrad_workspace_bytes': (_sz, [_i, _i, _i]),
     'rovit_wgrad': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'rovit_wgrad_multi': (_i, [_vp] * 7 + [_i, _i, _i, _vp]),
     'rovit_wgrad_reduce': (_i, [_vp, _i, _i, _i] + [_vp] * 8 + [_vp]),
     'rovit_attention_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     'rovit_attention_bwd': (_i, [_vp] * 5 + [_i] * 4 + [_f, _vp]),

@@ -12,7 +12,7 @@
 //                       a second ring for the elementwise factor, fc2 dgrad x gelu'
 //   gemm_kdma_kernel    K = 576: 12 waves x 16 columns over the whole K, LDS-DMA ring, row-wise epilogue
 //                       (qkv dgrad + LayerNorm backward)
-//   wgrad_kernel, wgrad_reduce_batch_kernel, wgrad_affine_batch_kernel, wgrad_affine_finalize_kernel
+//   wgrad_kernel, wgrad_reduce_batch_kernel (slab sums + LayerNorm-affine un-fold), wgrad_affine_finalize_kernel
 //
 // Reference arithmetic being restated: timm VisionTransformer's Linear layers (qkv/proj/fc1/fc2, patch-embed
 // conv as an im2col GEMM) reached through /root/reference/models/backbone.py:12-25, and their autograd
@@ -1407,67 +1407,70 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
 //   dbeta = sum_n W db  (finished by the affine kernel, which needs the complete db).
 struct ReduceBatch { RovitReduceDesc d[ROVIT_REDUCE_BATCH]; int first_block[ROVIT_REDUCE_BATCH + 1]; int n; };
 
+// Plain problems: thread = 4 consecutive elements of the flattened (N, K) gradient, summed over the slabs in split order.
+// Problems with a folded LayerNorm affine (gamma != NULL; N % 16 == 0, K % 64 == 0): a workgroup owns 16 rows x 64 columns,
+// so that the un-folding (dW = gamma*G + beta (x) db, and the per-column sums dgamma = sum_n W G, dbeta = sum_n W db) happens
+// in the same pass: the raw G never goes back to memory (round 1 wrote it to a scratch buffer and ran a second kernel over it).
+// Column sums leave the workgroup as one partial per 16-row group, combined in row order by the finalize kernel
+// (deterministic: no float atomics).
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBatch rb) {
+  __shared__ float s_pg[16][64], s_pb[16][64];
   int i = 0;
   while (i + 1 < rb.n && (int)blockIdx.x >= rb.first_block[i + 1]) ++i;
   const RovitReduceDesc& d = rb.d[i];
   const float* slab = d.ws;
   const float* colsum = d.ws + (size_t)d.splits * d.N * d.K;
-  const int q = ((int)blockIdx.x - rb.first_block[i]) * 256 + threadIdx.x;
-  const int total4 = d.N * d.K / 4;
-  if (q < total4) {
-    const float4* sp = (const float4*)slab + q;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-    for (int j = 0; j < d.splits; ++j) {
-      const float4 v = sp[(size_t)j * total4];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    // folded weights: keep the raw G; dW = gamma*G + beta (x) db is finished by the affine kernel (needs db)
-    ((float4*)(d.gamma ? d.g_scratch : d.dW))[q] = s;
-  }
-  if (q < d.N) {
-    float cb = 0.f;
-#pragma unroll 8
-    for (int j = 0; j < d.splits; ++j) cb += colsum[(size_t)j * d.N + q];
-    d.db[q] = cb;
-  }
-}
-
-constexpr int AFFINE_SLICES = 8;
-__global__ __launch_bounds__(256) void wgrad_affine_batch_kernel(const ReduceBatch rb) {
-  __shared__ float s_g[8][32], s_b[8][32];
-  int i = 0;
-  while (i + 1 < rb.n && (int)blockIdx.x >= rb.first_block[i + 1]) ++i;
-  const RovitReduceDesc& d = rb.d[i];
-  const int kc = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int local = (int)blockIdx.x - rb.first_block[i];
-  const int k = (local / AFFINE_SLICES) * 32 + kc;
-  const int sl = local % AFFINE_SLICES;                  // this block's slice of the rows n
-  const int n_lo = (int)((long)d.N * sl / AFFINE_SLICES), n_hi = (int)((long)d.N * (sl + 1) / AFFINE_SLICES);
-  float sg = 0.f, sb = 0.f;
-  if (k < d.K) {
-    const float gam = d.gamma[k], bet = d.beta[k];
-#pragma unroll 4
-    for (int n = n_lo + grp; n < n_hi; n += 8) {
-      const float w = d.W[(size_t)n * d.K + k];
-      const float G = d.g_scratch[(size_t)n * d.K + k];
-      const float cb = d.db[n];
-      d.dW[(size_t)n * d.K + k] = fmaf(gam, G, bet * cb);
-      sg = fmaf(w, G, sg);
-      sb = fmaf(w, cb, sb);
+  if (!d.gamma) {
+    const int q = local * 256 + threadIdx.x;
+    const int total4 = d.N * d.K / 4;
+    if (q < total4) {
+      const float4* sp = (const float4*)slab + q;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+      for (int j = 0; j < d.splits; ++j) {
+        const float4 v = sp[(size_t)j * total4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      ((float4*)d.dW)[q] = s;
     }
+    if (q < d.N) {
+      float cb = 0.f;
+#pragma unroll 8
+      for (int j = 0; j < d.splits; ++j) cb += colsum[(size_t)j * d.N + q];
+      d.db[q] = cb;
+    }
+    return;
   }
-  s_g[grp][kc] = sg; s_b[grp][kc] = sb;
+  const int kb = d.K / 64;
+  const int rblk = local / kb, kblk = local - rblk * kb;
+  const int r = threadIdx.x >> 4, kq = threadIdx.x & 15;
+  const int n = rblk * 16 + r, k = kblk * 64 + kq * 4;
+  const size_t e = (size_t)n * d.K + k;
+  const size_t stride = (size_t)d.N * d.K;
+  float4 G = make_float4(0.f, 0.f, 0.f, 0.f);
+  float cb = 0.f;
+#pragma unroll 8
+  for (int j = 0; j < d.splits; ++j) {
+    const float4 v = *(const float4*)(slab + (size_t)j * stride + e);
+    G.x += v.x; G.y += v.y; G.z += v.z; G.w += v.w;
+    cb += colsum[(size_t)j * d.N + n];
+  }
+  const float4 gam = *(const float4*)(d.gamma + k), bet = *(const float4*)(d.beta + k), w = *(const float4*)(d.W + e);
+  *(float4*)(d.dW + e) = make_float4(fmaf(gam.x, G.x, bet.x * cb), fmaf(gam.y, G.y, bet.y * cb), fmaf(gam.z, G.z, bet.z * cb),
+                                     fmaf(gam.w, G.w, bet.w * cb));
+  if (kblk == 0 && kq == 0) d.db[n] = cb;
+  *(float4*)&s_pg[r][kq * 4] = make_float4(w.x * G.x, w.y * G.y, w.z * G.z, w.w * G.w);
+  *(float4*)&s_pb[r][kq * 4] = make_float4(w.x * cb, w.y * cb, w.z * cb, w.w * cb);
   __syncthreads();
-  if (grp == 0 && k < d.K) {
+  if (threadIdx.x < 64) {
+    float sg = 0.f, sb = 0.f;
 #pragma unroll
-    for (int j = 1; j < 8; ++j) { sg += s_g[j][kc]; sb += s_b[j][kc]; }
-    // AFFINE_SLICES partial sums per column, combined in slice order by the finalize kernel (deterministic: no
-    // float atomics).  Scratch = the head of the slab workspace, which the reduce kernel has finished reading.
-    float* part = const_cast<float*>(d.ws);
-    part[(size_t)sl * d.K + k] = sg;
-    part[(size_t)(AFFINE_SLICES + sl) * d.K + k] = sb;
+    for (int rr = 0; rr < 16; ++rr) { sg += s_pg[rr][threadIdx.x]; sb += s_pb[rr][threadIdx.x]; }
+    const int slices = d.N / 16;
+    float* part = d.g_scratch;                 // [2][N/16][K] partial column sums (the scratch holds N*K floats)
+    part[(size_t)rblk * d.K + kblk * 64 + threadIdx.x] = sg;
+    part[(size_t)(slices + rblk) * d.K + kblk * 64 + threadIdx.x] = sb;
   }
 }
 
@@ -1477,10 +1480,11 @@ __global__ __launch_bounds__(256) void wgrad_affine_finalize_kernel(const Reduce
   const RovitReduceDesc& d = rb.d[i];
   const int k = ((int)blockIdx.x - rb.first_block[i]) * 256 + threadIdx.x;
   if (k >= d.K) return;
-  const float* part = d.ws;
+  const float* part = d.g_scratch;
+  const int slices = d.N / 16;
   float sg = 0.f, sb = 0.f;
-#pragma unroll
-  for (int sl = 0; sl < AFFINE_SLICES; ++sl) { sg += part[(size_t)sl * d.K + k]; sb += part[(size_t)(AFFINE_SLICES + sl) * d.K + k]; }
+#pragma unroll 4
+  for (int sl = 0; sl < slices; ++sl) { sg += part[(size_t)sl * d.K + k]; sb += part[(size_t)(slices + sl) * d.K + k]; }
   d.dgamma[k] = sg;
   d.dbeta[k] = sb;
 }
@@ -1665,34 +1669,31 @@ extern "C" int rovit_wgrad_reduce(const float* ws, int splits, int N, int K, con
 int rovit_wgrad_reduce_batch(const RovitReduceDesc* descs, int n, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(descs && n > 0 && n <= ROVIT_REDUCE_BATCH, ROVIT_ERR_SHAPE, "wgrad_reduce_batch: bad batch size %d", n);
   ReduceBatch rb{}, ab{};
-  int blocks = 0, ablocks = 0;
+  int blocks = 0, fblocks = 0;
   for (int i = 0; i < n; ++i) {
     const RovitReduceDesc& d = descs[i];
     ROVIT_CHECK_ARG(d.ws && d.dW && d.db, ROVIT_ERR_NULL, "wgrad_reduce_batch: null pointer");
     rb.d[i] = d;
     rb.first_block[i] = blocks;
-    const int nthreads = d.N * d.K / 4 > d.N ? d.N * d.K / 4 : d.N;
-    blocks += (nthreads + 255) / 256;
     if (d.gamma) {
       ROVIT_CHECK_ARG(d.beta && d.W && d.dgamma && d.dbeta && d.g_scratch, ROVIT_ERR_NULL, "wgrad_reduce_batch: affine un-fold needs beta/W/outputs");
+      ROVIT_CHECK_ARG(d.N % 16 == 0 && d.K % 64 == 0 && 2 * (d.N / 16) <= d.N, ROVIT_ERR_SHAPE, "wgrad_reduce_batch: affine un-fold needs N %% 16 == 0, K %% 64 == 0");
+      blocks += (d.N / 16) * (d.K / 64);
       ab.d[ab.n] = d;
-      ab.first_block[ab.n] = ablocks;
-      ablocks += (d.K + 31) / 32 * AFFINE_SLICES;
+      ab.first_block[ab.n] = fblocks;
+      fblocks += (d.K + 255) / 256;
       ab.n++;
+    } else {
+      const int nthreads = d.N * d.K / 4 > d.N ? d.N * d.K / 4 : d.N;
+      blocks += (nthreads + 255) / 256;
     }
   }
   rb.n = n; rb.first_block[n] = blocks;
-  ab.first_block[ab.n] = ablocks;
+  ab.first_block[ab.n] = fblocks;
   hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rb);
   ROVIT_CHECK_LAUNCH("wgrad_reduce_batch_kernel");
   if (ab.n > 0) {
-    hipLaunchKernelGGL(wgrad_affine_batch_kernel, dim3(ablocks), dim3(256), 0, (hipStream_t)stream, ab);
-    ROVIT_CHECK_LAUNCH("wgrad_affine_batch_kernel");
-    ReduceBatch fb = ab;
-    int fblocks = 0;
-    for (int i = 0; i < fb.n; ++i) { fb.first_block[i] = fblocks; fblocks += (fb.d[i].K + 255) / 256; }
-    fb.first_block[fb.n] = fblocks;
-    hipLaunchKernelGGL(wgrad_affine_finalize_kernel, dim3(fblocks), dim3(256), 0, (hipStream_t)stream, fb);
+    hipLaunchKernelGGL(wgrad_affine_finalize_kernel, dim3(fblocks), dim3(256), 0, (hipStream_t)stream, ab);
     ROVIT_CHECK_LAUNCH("wgrad_affine_finalize_kernel");
   }
   return ROVIT_OK;

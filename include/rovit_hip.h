@@ -116,6 +116,13 @@ int rovit_vit_forward_taps(const float* images, const float* const* params, cons
                            void* const* attn_taps, float* const* prob_taps, int batch, int depth, rovit_stream_t stream);
 int rovit_vit_backward(const float* d_features, const float* const* params, const void* prep, void* workspace,
                        float* const* grads, int batch, int depth, int first_block, int last_block, rovit_stream_t stream);
+/* fp32 reference-precision forward (inference only; parity / evaluation mode, not the fast path): the same arithmetic
+ * with every operand, product and sum in fp32 -- the mode in which BASELINE.json's "logits/severity within 1e-3 (fp32),
+ * class argmax bit-exact" is checked end to end.  params: the ORIGINAL fp32 parameters (no prepared weights);
+ * workspace: rovit_vit_f32_workspace_bytes(batch) bytes. */
+size_t rovit_vit_f32_workspace_bytes(int batch);
+int rovit_vit_forward_f32(const float* images, const float* const* params, void* workspace, float* features, int batch, int depth,
+                          rovit_stream_t stream);
 /* Where a saved activation / backward temporary of block `block` lives inside a TRAINING workspace
  * (rovit_vit_workspace_bytes(batch, depth, 1)): byte offset in *offset, extent in *bytes.  This is what the
  * explainability taps read (reference explainability/gradcam.py:18-60 hooks blocks[-1].norm1 for activations and

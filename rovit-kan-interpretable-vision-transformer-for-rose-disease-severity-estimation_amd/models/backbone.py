@@ -107,6 +107,9 @@ class DeiTTiny(nn.Module):
         self.blocks = nn.ModuleList(_Block() for _ in range(depth))
         self.norm = _LayerNorm(EMBED_DIM, eps=1e-6)
         self._engine = None
+        # 'bf16' (default): bf16 MFMA operands, fp32 accumulation -- the training / fast path.  'fp32': inference-only
+        # reference-precision mode (rovit_vit_forward_f32: every product and sum in fp32) for end-to-end parity at 1e-3.
+        self.precision = 'bf16'
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -132,7 +135,27 @@ class DeiTTiny(nn.Module):
             self._engine = VitEngine(self.depth)
         return self._engine
 
+    def _forward_fp32(self, x: torch.Tensor) -> torch.Tensor:
+        from rovit_hip import native
+        from rovit_hip.native import call, ptr, ptr_array, stream_ptr
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise native.RovitHipError("precision='fp32' is an inference-only parity mode: call it under torch.no_grad() "
+                                       '(training runs on the bf16 MFMA path)')
+        x = x.detach().float().contiguous()
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, IMG, IMG):
+            raise native.RovitHipError(f'backbone expects (B,3,224,224) images, got {tuple(x.shape)}')
+        B = x.shape[0]
+        params = [p.detach().float().contiguous() for p in self.ordered_parameters()]
+        ws = torch.empty(native.load().rovit_vit_f32_workspace_bytes(B), dtype=torch.uint8, device=x.device)
+        feats = torch.empty(B, EMBED_DIM, device=x.device, dtype=torch.float32)
+        call('rovit_vit_forward_f32', ptr(x), ptr_array(params), ptr(ws), ptr(feats), B, self.depth, stream_ptr())
+        return feats
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.precision == 'fp32':
+            return self._forward_fp32(x)
+        if self.precision != 'bf16':
+            raise ValueError(f"precision must be 'bf16' or 'fp32', got {self.precision!r}")
         training = torch.is_grad_enabled()
         attn_hooked = [i for i, b in enumerate(self.blocks) if b.attn._forward_hooks]
         norm_fwd = [i for i, b in enumerate(self.blocks) if b.norm1._forward_hooks]

@@ -34,6 +34,8 @@ SIGNATURES = {
     'rovit_vit_num_params': (_i, [_i]),
     'rovit_vit_prep_bytes': (_sz, [_i]),
     'rovit_vit_workspace_bytes': (_sz, [_i, _i, _i]),
+    'rovit_vit_f32_workspace_bytes': (_sz, [_i]),
+    'rovit_vit_forward_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     'rovit_vit_workspace_field': (_i, [_i, _i, _i, _i, _vp, _vp]),
     'rovit_vit_prepare': (_i, [_vp, _vp, _i, _vp]),
     'rovit_vit_forward': (_i, [_vp] * 5 + [_i] * 3 + [_vp]),

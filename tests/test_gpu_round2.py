@@ -508,3 +508,84 @@ def test_fp32_reference_precision_mode_meets_north_star_tolerances_end_to_end():
         m(x[:2].to(dev()))
     m.backbone.model.precision = 'bf16'
     assert m(x[:2].to(dev()))['features'].requires_grad
+
+
+def _dp_rank(rank, world, port, path, root, pkg):
+    import os
+    import sys
+    for p in (root, pkg):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from models.rovit_kan import RoViTKAN
+        from rovit_hip.losses import JointLoss
+        from rovit_hip.parallel import GradSync
+        blob = torch.load(path, weights_only=True)
+        d = torch.device('cuda:0')
+        torch.manual_seed(1234 + rank)                      # different initial weights: GradSync broadcasts rank 0's
+        m = RoViTKAN(pretrained=False)
+        if rank == 0:
+            m.load_state_dict(blob['sd'])
+        m = m.to(d).eval()
+        sync = GradSync(m, buckets=3)
+        assert sync.active and sync.world == world
+        per = blob['x'].shape[0] // world
+        x = blob['x'][rank * per:(rank + 1) * per].to(d)
+        y = blob['y'][rank * per:(rank + 1) * per].to(d)
+        out = m(x)
+        JointLoss()(out, y, y, 4)['total_loss'].backward()
+        sync.finish()
+        torch.cuda.synchronize()
+        g = torch.cat([p.grad.flatten() for p in m.parameters()]).cpu()
+        torch.save({'g': g, 'issued': len(sync.reducer.issued)}, f'{path}.rank{rank}')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_world2_on_the_real_backward_gloo_over_one_gpu():
+    """The only multi-rank run this box allows: TWO processes on the one GPU, gloo for the exchange, the REAL HIP
+    forward/backward with its block-range hooks and deferred-join schedule (RCCL needs one device per rank, so the
+    collective itself is gloo here).  Averaged gradients of the two half-batches must equal the single-process gradients
+    of the whole batch (loss terms are batch means), with rank 1 starting from different weights (broadcast at start)."""
+    import os
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    from models.rovit_kan import RoViTKAN
+    from rovit_hip.losses import JointLoss
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, 'rovit-kan-interpretable-vision-transformer-for-rose-disease-severity-estimation_amd')
+    torch.manual_seed(7)
+    sd = ref_cpu.init_rovit_state(seed=21)
+    x = torch.randn(8, 3, 224, 224)
+    y = torch.randint(0, 4, (8,))
+    m = _full_model(sd).eval()
+    out = m(x.to(dev()))
+    JointLoss()(out, y.to(dev()), y.to(dev()), 4)['total_loss'].backward()
+    g_ref = torch.cat([p.grad.flatten() for p in m.parameters()]).cpu()
+    del m, out
+    torch.cuda.empty_cache()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, 'blob.pt')
+        torch.save({'sd': sd, 'x': x, 'y': y}, path)
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        ctx = mp.get_context('spawn')
+        procs = [ctx.Process(target=_dp_rank, args=(r, 2, port, path, root, pkg)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=300)
+            assert p.exitcode == 0
+        res = [torch.load(f'{path}.rank{r}', weights_only=True) for r in range(2)]
+    assert torch.equal(res[0]['g'], res[1]['g'])                      # both ranks hold the same averaged gradients
+    assert res[0]['issued'] == 4                                      # three backbone buckets + the head/KAN bucket
+    scale = float(g_ref.abs().max())
+    err = float((res[0]['g'] - g_ref).abs().max())
+    cos = float(torch.nn.functional.cosine_similarity(res[0]['g'], g_ref, dim=0))
+    print(f'world-2 averaged gradients vs single process: max |err| {err:.3e} (scale {scale:.3e}), cosine {cos:.7f}')
+    assert err < 2e-3 * scale and cos > 0.99999

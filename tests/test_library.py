@@ -96,3 +96,47 @@ def test_module_surface_matches_reference_contract(native):
             num_classes = 4
     assert RoViTKAN(Cfg).count_parameters()['total'] == 5706394
     assert len([n for n, _ in m.named_parameters() if 'backbone' in n]) == 6 + 12 * 12
+
+
+def test_synthetic_dataset_and_loaders_on_cpu():
+    """data.dataset: calling conventions of scripts/train.py:73-84,110-111 and evaluate.py:40-46,
+    synthetic mode, class weights, seeded split; no GPU needed (device='cpu')."""
+    import torch
+    from data.dataset import RoseLeafDataset, create_dataloaders, DeviceBatchLoader
+    from data.transforms import augmented_transforms, original_transforms
+    names = ["Healthy Leaf", "Leaf Holes", "Black Spot", "Dry Leaf"]
+    sev = {n: i for i, n in enumerate(names)}
+    tr, va, te = create_dataloaders(augmented_root='nope/Augmented Image', original_root='nope/Original Image', class_names=names,
+                                    severity_map=sev, augmented_transform=augmented_transforms(), original_transform=original_transforms(),
+                                    batch_size=8, train_val_split=0.8, num_workers=0, seed=3, synthetic=50, device=torch.device('cpu'))
+    assert isinstance(tr, DeviceBatchLoader) and len(tr) == 5 and len(va) == 2 and len(te) == 2
+    base = tr.dataset.dataset
+    assert isinstance(base, RoseLeafDataset) and len(base) == 50
+    w = base.get_class_weights()
+    assert w.shape == (4,) and abs(float(w.mean()) - 1.0) < 0.2
+    seen = 0
+    for x, c, s in tr:
+        assert x.shape[1:] == (3, 224, 224) and x.dtype == torch.float32 and torch.equal(c, s)
+        seen += x.shape[0]
+    assert seen == 40
+    tr2, _, _ = create_dataloaders(None, None, names, sev, batch_size=8, seed=3, synthetic=50, device=torch.device('cpu'))
+    assert tr2.dataset.indices == tr.dataset.indices                 # seeded split
+    img, c, s = RoseLeafDataset(None, names, sev, None, 'original', synthetic=5)[2]
+    assert img.shape == (3, 224, 224) and int(s) == sev[names[int(c)]]
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        RoseLeafDataset('does/not/exist', names, sev)
+
+
+def test_hooks_that_cannot_fire_are_refused():
+    import pytest
+    from models.backbone import DeiTTiny
+    m = DeiTTiny(1)
+    for mod in (m.blocks[0].mlp.fc1, m.blocks[0].attn.qkv, m.blocks[0].norm2, m.patch_embed, m.norm, m.blocks[0].mlp, m.blocks[0]):
+        with pytest.raises(NotImplementedError):
+            mod.register_forward_hook(lambda *a: None)
+    m.blocks[0].norm1.register_forward_hook(lambda *a: None).remove()            # supported taps register fine
+    m.blocks[0].norm1.register_full_backward_hook(lambda *a: None).remove()
+    m.blocks[0].attn.register_forward_hook(lambda *a: None).remove()
+    with pytest.raises(NotImplementedError):
+        m.blocks[0].attn.register_full_backward_hook(lambda *a: None)

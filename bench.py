@@ -38,11 +38,24 @@ def build_optimizer(model, lr=1e-4, wd=1e-4):
     return torch.optim.AdamW([{'params': bb, 'lr': lr / 10}, {'params': hd, 'lr': lr}], weight_decay=wd)
 
 
+def _warm_clocks(dev, seconds=0.3):
+    """Keep the device busy with a library GEMM (a kernel of another name, so the profiles of the measured kernels hold
+    only their own launches) until the clocks have left the idle state: the first ~100 ms after an idle period run
+    10-15 % slower (measured: the same launch 109 us cold against 95 us after the training loop)."""
+    a = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            a @ a
+        torch.cuda.synchronize(dev)
+
+
 def _event_avg_ms(dev, run, iters, per_launch=True):
     """Average duration of one call of `run` from device events on the stream it launches on.  per_launch=True brackets
     EVERY launch with its own pair of events (a kernel's whole life, first workgroup in to last workgroup out -- what
     rocprofv3 --kernel-trace reports per dispatch); per_launch=False times the back-to-back train, where one launch's
     ramp hides in the previous launch's tail (throughput view; 10-18 % shorter for these 20-100 us kernels)."""
+    _warm_clocks(dev)
     for _ in range(5):
         run()
     st = torch.cuda.current_stream(dev)

@@ -128,10 +128,16 @@ def test_full_model_forward_all_stages_vs_oracle():
                 continue
             assert err < BF16_TOL, (stage, k, err)
             assert float((out[k].cpu() - r).pow(2).mean().sqrt()) < BF16_RMS, (stage, k)
-        # class argmax: identical wherever the oracle's top-2 margin exceeds the stated tolerance
+        # class argmax: identical wherever the oracle's top-2 margin exceeds twice the MEASURED logit error of this run
+        # (the stated 5e-2 bound would exclude every sample of a random-init model, whose margins are ~1e-2: the
+        # comparison must not be vacuous); excluded samples are counted
+        lerr = float((out['cls_logits'].cpu() - ref['cls_logits']).abs().max())
         top2 = ref['cls_logits'].topk(2, dim=1).values
-        decided = (top2[:, 0] - top2[:, 1]) > 2 * BF16_TOL
-        print(f'stage {stage}: class argmax compared on {int(decided.sum())} of {decided.numel()} samples (oracle top-2 margin > {2 * BF16_TOL})')
+        decided = (top2[:, 0] - top2[:, 1]) > 2 * lerr
+        agree = int((out['cls_logits'].cpu().argmax(1) == ref['cls_logits'].argmax(1)).sum())
+        print(f'stage {stage}: class argmax compared on {int(decided.sum())} of {decided.numel()} samples (oracle top-2 margin > '
+              f'2 x {lerr:.4f}), {int((~decided).sum())} excluded; agreement on all samples {agree}/{decided.numel()}')
+        assert int(decided.sum()) >= decided.numel() // 2, 'argmax comparison is vacuous'
         assert torch.equal(out['cls_logits'].cpu().argmax(1)[decided], ref['cls_logits'].argmax(1)[decided])
         # fp32 heads / KAN given the SAME features: north_star's 1e-3
         f = out['features'].cpu()

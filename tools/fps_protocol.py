@@ -9,7 +9,8 @@ from models.rovit_kan import RoViTKAN
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
 m = RoViTKAN(pretrained=False).to(dev).eval()
-for B, warm, n in ((1, 10, 100), (256, 5, 30)):
+for prec, B, warm, n in (('bf16', 1, 10, 100), ('bf16', 256, 5, 30), ('fp32', 1, 10, 100), ('fp32', 256, 3, 10)):
+    m.backbone.model.precision = prec
     x = torch.randn(B, 3, 224, 224, device=dev)
     with torch.no_grad():
         for _ in range(warm):
@@ -20,4 +21,4 @@ for B, warm, n in ((1, 10, 100), (256, 5, 30)):
             m(x)
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f'batch {B}: {n * B / dt:9.1f} images/s  ({dt / n * 1e3:.3f} ms per forward, stage 4, eval)')
+    print(f'{prec} batch {B}: {n * B / dt:9.1f} images/s  ({dt / n * 1e3:.3f} ms per forward, stage 4, eval)')

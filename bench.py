@@ -148,7 +148,7 @@ def gemm_roofline(dev, iters=30):
 def kan_roofline(dev, iters=30):
     """KAN spline head (north_star: HBM roofline, no MFMA), kernels only (direct C-ABI calls):
     C5 = BASELINE.json configs[4] (num_knots 32, batch 512: three per-layer launches, the faster path at that size) and
-    the streaming shape batch 65536 (one fused launch, rovit_kan_stack_fwd).  Algorithmic bytes: the
+    the streaming shapes batch 65536 (one launch on the matrix cores, rovit_kan_stack_fwd_mfma).  Algorithmic bytes: the
     weights once per launch + x and every layer output once."""
     import ctypes as C
     from models.kan import KANSeverityModule
@@ -158,7 +158,7 @@ def kan_roofline(dev, iters=30):
     lib = native.load()
     layers = [192, 64, 16, 1]
     res = {}
-    for key, G, B in (('c5_g32_b512', 32, 512), ('stream_g5_b65536', 5, 65536), ('c3_g5_b256', 5, 256)):
+    for key, G, B in (('c5_g32_b512', 32, 512), ('stream_g5_b65536', 5, 65536), ('stream_g32_b65536', 32, 65536), ('c3_g5_b256', 5, 256)):
         m = KANSeverityModule(layers, G, 3).to(dev)
         nb, n = G + 2, 3
         x = torch.randn(B, 192, device=dev)
@@ -166,7 +166,14 @@ def kan_roofline(dev, iters=30):
         arr = lambda xs: (C.c_int * len(xs))(*xs)
         sp = native.stream_ptr()
         fused = B >= m.fused_min_batch
-        if fused:
+        mfma = fused and B >= m.mfma_min_batch and all(p[2] is not None for p in m._prepared())
+        if mfma:
+            prep = m._prepared()
+            margs = (ptr(x), ptr_array([p[2] for p in prep]), ptr_array([l.knots for l in m.kan_layers]),
+                     ptr_array([l.linear.bias for l in m.kan_layers]), ptr_array(outs), B, arr(layers),
+                     arr([l.knots.numel() for l in m.kan_layers]), arr([ACT_RELU, ACT_RELU, ACT_SIGMOID3]), n, sp)
+            run = lambda: lib.rovit_kan_stack_fwd_mfma(*margs)
+        elif fused:
             prep = m._prepared()
             args = (ptr(x), ptr_array([p[0] for p in prep]), ptr_array([l.knots for l in m.kan_layers]), ptr_array([p[1] for p in prep]),
                     ptr_array([l.linear.bias for l in m.kan_layers]), ptr_array(outs), B, arr(layers),
@@ -185,9 +192,17 @@ def kan_roofline(dev, iters=30):
         act_bytes = B * (layers[0] + (sum(layers[1:]) if fused else 2 * sum(layers[1:-1]) + layers[-1])) * 4
         alg = float(w_bytes + act_bytes)
         gbs = alg / (ms * 1e-3) / 1e9
-        res[key] = {'bound': 'hbm', 'kernel': 'kan_stack_fwd_kernel (one launch)' if fused else 'kan_fwd_kernel x3 (per layer)',
+        kname = ('kan_stack_mfma_kernel (one launch, fp32 MFMA)' if mfma else 'kan_stack_fwd_kernel (one launch)' if fused
+                 else 'kan_fwd_kernel x3 (per layer)')
+        res[key] = {'bound': 'hbm', 'kernel': kname,
                     'num_knots': G, 'batch': B, 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(gbs / HBM_PEAK_GBS, 5), 'avg_us': round(ms * 1e3, 2), 'algorithmic_bytes': alg, 'traffic': None}
+                    'frac': round(gbs / HBM_PEAK_GBS, 5), 'avg_us': round(ms * 1e3, 2), 'algorithmic_bytes': alg,
+                    'traffic': _pmc_traffic(f'kan_stack_mfma_kernel<{4 if G == 5 else 18}>') if mfma else None}
+        if mfma:   # dense matrix-core work (structural zeros included) against the fp32 MFMA peak, for the record
+            S = 8 if G == 5 else 36
+            mf = 2.0 * B * sum(a * S * 32 * (2 if b > 32 else 1) for a, b in zip(layers[:-1], layers[1:]))
+            res[key]['mfma_f32_tflops'] = round(mf / (ms * 1e-3) / 1e12, 1)
+            res[key]['mfma_frac_of_f32_matrix_peak'] = round(mf / (ms * 1e-3) / 1e12 / 157.3, 4)
     return res
 
 

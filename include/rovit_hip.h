@@ -69,6 +69,17 @@ int rovit_kan_prepare(const float* spline_w, const float* lin_w, float* spline_w
 int rovit_kan_stack_fwd(const float* x, const float* const* spline_wt, const float* const* knots, const float* const* lin_wt,
                         const float* const* lin_b, float* const* outs, int batch, const int* dims, const int* n_knots,
                         const int* acts, int n_layers, rovit_stream_t stream);
+/* The same stack on the matrix cores for large batches (models/kan.py:70-95 as the dense contraction
+ * sum_j sum_s R[b,j,s] Wd[j,s,o]: slots s = the num_basis truncated-basis values of tanh(x_j) followed by the raw x_j of
+ * the layer's Linear term; v_mfma_f32_32x32x2_f32, fp32 operands and accumulation).  rovit_kan_mfma_prepared_floats gives
+ * the size of one layer's prepared weight layout, or 0 when the kernel does not cover the layer (it covers in_f % 8 == 0,
+ * out_f <= 64 and n_basis 7 or 34, i.e. num_knots 5 and 32 of the reference's configs); rovit_kan_prepare_mfma fills it
+ * (re-run whenever the parameters change); wm / knots / lin_b / outs are HOST arrays of n_layers device pointers. */
+size_t rovit_kan_mfma_prepared_floats(int in_f, int out_f, int n_basis);
+int rovit_kan_prepare_mfma(const float* spline_w, const float* lin_w, float* wm, int in_f, int out_f, int n_basis, rovit_stream_t stream);
+int rovit_kan_stack_fwd_mfma(const float* x, const float* const* wm, const float* const* knots, const float* const* lin_b,
+                             float* const* outs, int batch, const int* dims, const int* n_knots, const int* acts, int n_layers,
+                             rovit_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * MLP heads.  rovit_linear_* are the building block (nn.Linear [+ReLU] [*dropout mask] [clamp +-10]);

@@ -259,6 +259,211 @@ __global__ __launch_bounds__(256) void kan_prepare_kernel(const float* __restric
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Dense matrix-core form of the same stack for LARGE batches (VERDICT r1 item 6 / DESIGN.md section 4):
+//   layer(x)[b, o] = sum_j sum_s R[b, j, s] * Wd[j, s, o] + bias[o],   s = 0 .. 2H-1 "slots" of input feature j:
+//   slots 0 .. nb-1 = the truncated cubic basis values B_s(tanh x[b, j]) (four of them non-zero), slot nb = the raw x[b, j]
+//   (the layer's Linear term), the rest zero padding.  The contraction over (j, s) runs on v_mfma_f32_32x32x2_f32: fp32
+//   operands and accumulation, i.e. the arithmetic class of the VALU kernels (only the summation order differs).  It
+//   multiplies the structural zeros too (8/5 of the useful FMAs at G = 5, 36/5 at G = 32) but leaves the LDS-fed VALU loop
+//   that bounds kan_stack_fwd_kernel.
+// One wave = one workgroup = 32 samples for the whole stack (no barrier ever joins two waves):
+//   M (rows of D) = 32 outputs of a tile, N (columns) = the 32 samples, K = 2 slots per instruction.
+//   A operand (weights): lane l holds Wm[.., kk = l / 32][o = l % 32], read straight from the prepared global layout
+//     Wm[j][q][t][kk][32] (rovit_kan_prepare_mfma): one coalesced 256-byte run per register, served by L1/L2 (all waves
+//     walk the same weights in the same order);
+//   B operand (slot values): lane l = (sample l % 32, kk = l / 32) reads its H values of slot parity kk from the dense
+//     row R[b, j, :] that the wave built in LDS (rows are zeroed, then the <= 5 live values are written at their slot);
+//   D: lane holds sample l % 32 and outputs 8 (r / 4) + 4 (l / 32) + r % 4 of the tile -> 16-byte stores.
+// Layer outputs stay in LDS as the next layer's input and go to HBM once (backward / trajectory).
+// ------------------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int KM_TS = 32;                  // samples per wave
+
+// Basis values on a UNIFORM grid (the reference's knots are torch.linspace, kan.py:59; the caller checks it): the
+// interval index comes from arithmetic instead of a search, its two knots are then read from the STORED fp32 knots (LDS),
+// so u is the value ks_basis computes whenever the index agrees.  The spline is C2 across interior knots, so an interval
+// chosen one ulp early or late moves the result by O(ulp^3); the ONE discontinuous decision -- x_c >= knots[nb] turns the
+// whole basis off -- and the clamp use the stored knot values exactly (kcut, t0, tl).
+__device__ __forceinline__ B4 km_basis(float xn, const float* knots, float t0, float tl, float kcut, float inv_h, int nb) {
+  B4 r;
+  const float xc = fminf(fmaxf(xn, t0), tl);
+  int j = (int)floorf((xc - t0) * inv_h);
+  j = j < 0 ? 0 : (j > nb - 1 ? nb - 1 : j);                  // a live sample sits left of knots[nb]
+  const float tj = knots[j], tj1 = knots[j + 1];
+  const float u = (xc - tj) / (tj1 - tj);
+  const float u2 = u * u, u3 = u2 * u, om = 1.f - u;
+  r.j = xc >= kcut ? -1 : j;
+  r.v[0] = u3 * (1.f / 6.f);
+  r.v[1] = (-3.f * u3 + 3.f * u2 + 3.f * u + 1.f) * (1.f / 6.f);
+  r.v[2] = (3.f * u3 - 6.f * u2 + 4.f) * (1.f / 6.f);
+  r.v[3] = om * om * om * (1.f / 6.f);
+  return r;
+}
+
+struct KanMfmaArgs {
+  const float* x; int B;
+  int nl;
+  int dims[KS_MAX_LAYERS + 1];
+  const float* Wm[KS_MAX_LAYERS];         // PREPARED [in][H][NT][2][32]
+  const float* knots[KS_MAX_LAYERS];
+  const float* lb[KS_MAX_LAYERS];
+  float* out[KS_MAX_LAYERS];
+  int nk[KS_MAX_LAYERS];
+  int act[KS_MAX_LAYERS];
+  int as0, as1;                           // LDS row strides (floats) of the two activation buffers: outputs of even / odd layers
+};
+
+// H = half the padded slot count; FPL = features per lane and sub-chunk (a super-chunk is 8 features: lane (sample, h)
+// owns features 4h .. 4h+3 of it and builds FPL of their rows per sub-chunk); NT = 32-output tiles of the layer.
+template <int H, int FPL, int NT, int L>
+__device__ __forceinline__ void km_layer(const KanMfmaArgs& a, float* s_knots, float* s_act, float* s_row, int lane, int b0) {
+  constexpr int l = L;
+  constexpr int S = 2 * H;
+  const int in_f = a.dims[l], out_f = a.dims[l + 1];
+  const int nk = a.nk[l], nb = nk - 4;
+  const int smp = lane & 31, hk = lane >> 5;
+  __syncthreads();
+  if (lane < nk) s_knots[lane] = a.knots[l][lane];
+  __syncthreads();
+  const float t0 = s_knots[0], tl = s_knots[nk - 1], kcut = s_knots[nb];
+  const float inv_h = (float)(nk - 1) / (tl - t0);
+  float* dummy = s_knots + KS_MAX_KNOTS + lane;              // sink of the scattered writes of absent basis terms
+  // activation buffers: outputs of even layers in buffer 0 (stride as0), of odd layers in buffer 1 (stride as1)
+  const int as_in = (l & 1) ? a.as0 : a.as1, as_out = (l & 1) ? a.as1 : a.as0;
+  const float* src = l == 0 ? nullptr : s_act + ((l & 1) ? 0 : KM_TS * a.as0) + smp * as_in;
+  const int bs = b0 + smp < a.B ? b0 + smp : a.B - 1;
+  const float* xrow = a.x + (size_t)bs * in_f;
+  const float* wl = a.Wm[l] + lane;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  f32x4 xn = l == 0 ? *(const f32x4*)(xrow + 4 * hk) : *(const f32x4*)(src + 4 * hk);
+  for (int i0 = 0; i0 < in_f; i0 += 8) {
+    const f32x4 xv4 = xn;
+    if (i0 + 8 < in_f) xn = l == 0 ? *(const f32x4*)(xrow + i0 + 8 + 4 * hk) : *(const f32x4*)(src + i0 + 8 + 4 * hk);
+#pragma unroll
+    for (int sc = 0; sc < 4 / FPL; ++sc) {
+      // ---- the sub-chunk's weights: issued first, they land while the rows are built
+      float wr[2 * FPL][H * NT];
+#pragma unroll
+      for (int f = 0; f < 2 * FPL; ++f) {
+        const int jin = i0 + 4 * (f & 1) + sc * FPL + (f >> 1);
+        const float* wp = wl + (size_t)jin * H * NT * 64;
+#pragma unroll
+        for (int e = 0; e < H * NT; ++e) wr[f][e] = wp[e * 64];
+      }
+      // ---- build the dense slot rows of this sub-chunk: local feature f = 2 * u + hk  <->  input i0 + 4 * hk + sc * FPL + u
+#pragma unroll
+      for (int u = 0; u < FPL; ++u) {
+        const float xv = xv4[sc * FPL + u];
+        const B4 bq = km_basis(tanhf(xv), s_knots, t0, tl, kcut, inv_h, nb);
+        float* row = s_row + ((2 * u + hk) * KM_TS + smp) * S;
+#pragma unroll
+        for (int z = 0; z < S / 4; ++z) *(f32x4*)(row + 4 * z) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // slot s lives at position (s & 1) * H + (s >> 1): the two slot parities are the two K rows of an MFMA step
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int sidx = bq.j - m;                         // < 0: left edge lost the term, or the sample is beyond the cutoff
+          float* dst = sidx >= 0 ? row + ((sidx & 1) * H + (sidx >> 1)) : dummy;
+          *dst = bq.v[m];
+        }
+        row[(nb & 1) * H + (nb >> 1)] = xv;
+      }
+      __syncthreads();
+      // ---- contraction of the 2 * FPL features of the sub-chunk
+#pragma unroll
+      for (int f = 0; f < 2 * FPL; ++f) {
+        const float* rp = s_row + (f * KM_TS + smp) * S + hk * H;
+        float bv[H];
+        if (H % 4 == 0) {
+#pragma unroll
+          for (int z = 0; z < H / 4; ++z) { const f32x4 v = *(const f32x4*)(rp + 4 * z); bv[4 * z] = v[0]; bv[4 * z + 1] = v[1]; bv[4 * z + 2] = v[2]; bv[4 * z + 3] = v[3]; }
+        } else {
+#pragma unroll
+          for (int z = 0; z < H / 2; ++z) { const float2 v = *(const float2*)(rp + 2 * z); bv[2 * z] = v.x; bv[2 * z + 1] = v.y; }
+        }
+#pragma unroll
+        for (int q = 0; q < H; ++q)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[f][q * NT + t], bv[q], acc[t], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+  // ---- bias, activation; hand the outputs to the next layer (LDS) and to HBM
+  float* dst = s_act + ((l & 1) ? KM_TS * a.as0 : 0) + smp * as_out;
+  const bool live = b0 + smp < a.B;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int o = 32 * t + 8 * g + 4 * hk;
+      float z[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[t][4 * g + e] + (o + e < out_f ? a.lb[l][o + e] : 0.f);
+        v = a.act[l] == ROVIT_ACT_RELU ? fmaxf(v, 0.f) : (a.act[l] == ROVIT_ACT_SIGMOID3 ? 3.f / (1.f + __expf(-v)) : v);
+        z[e] = v;
+      }
+      if (o < as_out) *(f32x4*)(dst + o) = (f32x4){z[0], z[1], z[2], z[3]};
+      if (live) {
+        if (o + 3 < out_f) *(f32x4*)(a.out[l] + (size_t)(b0 + smp) * out_f + o) = (f32x4){z[0], z[1], z[2], z[3]};
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (o + e < out_f) a.out[l][(size_t)(b0 + smp) * out_f + o + e] = z[e];
+      }
+    }
+}
+
+template <int H, int FPL, int L>
+__device__ __forceinline__ void km_layer_nt(const KanMfmaArgs& a, float* s_knots, float* s_act, float* s_row, int lane, int b0) {
+  if (a.dims[L + 1] > 32) km_layer<H, FPL, 2, L>(a, s_knots, s_act, s_row, lane, b0);
+  else km_layer<H, FPL, 1, L>(a, s_knots, s_act, s_row, lane, b0);
+}
+
+template <int H, int FPL>
+__global__ __launch_bounds__(64) void kan_stack_mfma_kernel(const KanMfmaArgs a) {
+  // 18.7 KB (G = 5) / 19.7 KB (G = 32) for the default stack: eight workgroups per CU, so that the 2048 waves of a
+  // 65536-sample batch are resident together (one more KB and a quarter of them would wait for a second round)
+  extern __shared__ __attribute__((aligned(16))) float km_smem[];
+  float* s_knots = km_smem;                                  // [64] knots + [64] write sink
+  float* s_row = s_knots + 2 * KS_MAX_KNOTS;                 // [2 FPL][32][2H]
+  float* s_act = s_row + 2 * FPL * KM_TS * 2 * H;            // [32][as0] + [32][as1]
+  const int lane = threadIdx.x;
+  const int b0 = blockIdx.x * KM_TS;
+  km_layer_nt<H, FPL, 0>(a, s_knots, s_act, s_row, lane, b0);
+  if (a.nl > 1) km_layer_nt<H, FPL, 1>(a, s_knots, s_act, s_row, lane, b0);
+  if (a.nl > 2) km_layer_nt<H, FPL, 2>(a, s_knots, s_act, s_row, lane, b0);
+  if (a.nl > 3) km_layer_nt<H, FPL, 3>(a, s_knots, s_act, s_row, lane, b0);
+}
+
+// half the padded slot count of a layer with nb basis functions (+1 slot for the Linear term), rounded up to even
+__host__ __device__ inline int km_half_slots(int nb) { const int h = (nb + 2) / 2; return (h + 1) & ~1; }
+
+// Wm[j][q][t][kk][o'] = Wd[j][s = 2q + kk][o = 32 t + o'],  Wd[j][s][o] = spline_w[j][o][s] (s < nb), lin_w[o][j] (s == nb), else 0
+__global__ __launch_bounds__(256) void kan_prepare_mfma_kernel(const float* __restrict__ w, const float* __restrict__ lw, float* __restrict__ wm,
+                                                               int in_f, int out_f, int nb, int H, int NT) {
+  const size_t n = (size_t)in_f * H * NT * 64;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const int op = (int)(e & 31), kk = (int)(e >> 5) & 1;
+    size_t r = e >> 6;
+    const int t = (int)(r % NT); r /= NT;
+    const int q = (int)(r % H);
+    const int j = (int)(r / H);
+    const int s = 2 * q + kk, o = 32 * t + op;
+    float v = 0.f;
+    if (o < out_f) v = s < nb ? w[((size_t)j * out_f + o) * nb + s] : (s == nb ? lw[(size_t)o * in_f + j] : 0.f);
+    wm[e] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int rovit_kan_prepare(const float* spline_w, const float* lin_w, float* spline_wt, float* lin_wt, int in_f, int out_f,
@@ -315,5 +520,65 @@ extern "C" int rovit_kan_stack_fwd(const float* x, const float* const* spline_w,
     hipLaunchKernelGGL(kan_stack_fwd_kernel<32>, dim3((batch + tb - 1) / tb), dim3(tb * KS_G), lds, (hipStream_t)stream, a);
   }
   ROVIT_CHECK_LAUNCH("kan_stack_fwd_kernel");
+  return ROVIT_OK;
+}
+
+// ---- matrix-core form (large batches) ------------------------------------------------------------------------------
+// floats of the prepared MFMA weight layout of one layer, or 0 when the layer shape is not supported by the kernel
+extern "C" size_t rovit_kan_mfma_prepared_floats(int in_f, int out_f, int n_basis) {
+  if (in_f <= 0 || out_f <= 0 || out_f > KS_MAXW || n_basis < 4 || in_f % 8 != 0) return 0;
+  const int H = km_half_slots(n_basis);
+  if (H != 4 && H != 18) return 0;                    // instantiated: G = 5 (7 basis -> 8 slots) and G = 32 (34 -> 36)
+  const int NT = out_f > 32 ? 2 : 1;
+  return (size_t)in_f * H * NT * 64;
+}
+
+extern "C" int rovit_kan_prepare_mfma(const float* spline_w, const float* lin_w, float* wm, int in_f, int out_f, int n_basis,
+                                      rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(spline_w && lin_w && wm, ROVIT_ERR_NULL, "kan_prepare_mfma: null pointer");
+  const size_t n = rovit_kan_mfma_prepared_floats(in_f, out_f, n_basis);
+  ROVIT_CHECK_ARG(n > 0, ROVIT_ERR_SHAPE, "kan_prepare_mfma: unsupported layer %d -> %d with %d basis functions", in_f, out_f, n_basis);
+  ROVIT_CHECK_ARG(rovit_aligned16(wm), ROVIT_ERR_ALIGN, "kan_prepare_mfma: output must be 16-byte aligned");
+  int blocks = (int)((n + 255) / 256);
+  blocks = blocks > 2048 ? 2048 : blocks;
+  hipLaunchKernelGGL(kan_prepare_mfma_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, spline_w, lin_w, wm, in_f, out_f, n_basis,
+                     km_half_slots(n_basis), out_f > 32 ? 2 : 1);
+  ROVIT_CHECK_LAUNCH("kan_prepare_mfma_kernel");
+  return ROVIT_OK;
+}
+
+// wm: HOST array of n_layers device pointers to the layouts of rovit_kan_prepare_mfma; other arguments as rovit_kan_stack_fwd.
+// All layers must share the knot count (one kernel instantiation per slot count).
+extern "C" int rovit_kan_stack_fwd_mfma(const float* x, const float* const* wm, const float* const* knots, const float* const* lin_b,
+                                        float* const* outs, int batch, const int* dims, const int* n_knots, const int* acts, int n_layers,
+                                        rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(x && wm && knots && lin_b && outs && dims && n_knots && acts, ROVIT_ERR_NULL, "kan_stack_fwd_mfma: null pointer");
+  ROVIT_CHECK_ARG(batch > 0 && n_layers >= 1 && n_layers <= KS_MAX_LAYERS, ROVIT_ERR_SHAPE, "kan_stack_fwd_mfma: 1..%d layers", KS_MAX_LAYERS);
+  ROVIT_CHECK_ARG(rovit_aligned16(x), ROVIT_ERR_ALIGN, "kan_stack_fwd_mfma: x must be 16-byte aligned");
+  KanMfmaArgs a{};
+  a.x = x; a.B = batch; a.nl = n_layers;
+  for (int l = 0; l <= n_layers; ++l) a.dims[l] = dims[l];
+  const int H = km_half_slots(n_knots[0] - 4);
+  for (int l = 0; l < n_layers; ++l) {
+    ROVIT_CHECK_ARG(wm[l] && knots[l] && lin_b[l] && outs[l], ROVIT_ERR_NULL, "kan_stack_fwd_mfma: null pointer in layer %d", l);
+    ROVIT_CHECK_ARG(n_knots[l] == n_knots[0] && n_knots[l] <= KS_MAX_KNOTS, ROVIT_ERR_SHAPE, "kan_stack_fwd_mfma: layers must share the knot count");
+    ROVIT_CHECK_ARG(rovit_kan_mfma_prepared_floats(dims[l], dims[l + 1], n_knots[l] - 4) > 0 && (l == 0 || dims[l] <= KS_MAXW), ROVIT_ERR_SHAPE,
+                    "kan_stack_fwd_mfma: unsupported layer %d: %d -> %d, %d knots", l, dims[l], dims[l + 1], n_knots[l]);
+    ROVIT_CHECK_ARG(rovit_aligned16(wm[l]) && rovit_aligned16(outs[l]) && (dims[l + 1] % 4 == 0 || dims[l + 1] < 4), ROVIT_ERR_ALIGN,
+                    "kan_stack_fwd_mfma: layer %d: buffers must be 16-byte aligned, widths a multiple of 4 (or < 4)", l);
+    a.Wm[l] = wm[l]; a.knots[l] = knots[l]; a.lb[l] = lin_b[l]; a.out[l] = outs[l]; a.nk[l] = n_knots[l]; a.act[l] = acts[l];
+  }
+  // activation rows hold whole 4-float groups of the widest layer they serve (a layer's 32-output tiles are cut at that width)
+  for (int l = 0; l < n_layers; ++l) {
+    const int w = (dims[l + 1] + 3) & ~3;
+    if (l & 1) a.as1 = w > a.as1 ? w : a.as1; else a.as0 = w > a.as0 ? w : a.as0;
+  }
+  if (a.as1 == 0) a.as1 = 4;
+  const int grid = (batch + KM_TS - 1) / KM_TS;
+  const int fpl = H == 4 ? 4 : 1;
+  const size_t lds = (2 * KS_MAX_KNOTS + (size_t)2 * fpl * KM_TS * 2 * H + (size_t)KM_TS * (a.as0 + a.as1)) * sizeof(float);
+  if (H == 4) hipLaunchKernelGGL((kan_stack_mfma_kernel<4, 4>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((kan_stack_mfma_kernel<18, 1>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
+  ROVIT_CHECK_LAUNCH("kan_stack_mfma_kernel");
   return ROVIT_OK;
 }

@@ -63,7 +63,13 @@ class KANSeverityModule(nn.Module):
         self.layers_dims, self.num_knots, self.degree = layers, num_knots, degree
         self.kan_layers = nn.ModuleList(KANLayer(a, b, num_knots, degree) for a, b in zip(layers[:-1], layers[1:]))
         self.activations = nn.ModuleList(nn.ReLU() for _ in range(len(layers) - 2))
-        self.fused_min_batch = 2048
+        # forward kernel by batch size (MI355X, kernels only, [192,64,16,1]; tools/bench_kan.py --sweep, profiles/r02_bench_kan_sweep.jsonl):
+        #   G=5:  per-layer 52 / 89 / 163 us at 1024 / 2048 / 4096; matrix-core stack 103 us flat up to 8192, 186 us at 65536
+        #         (VALU stack 114 us flat, 520 us at 65536)
+        #   G=32: per-layer 129 / 287 us at 1024 / 2048; VALU stack 213 us flat up to 16384, 446 / 884 us at 32768 / 65536;
+        #         matrix-core stack 314 us flat, 340 / 698 us at 32768 / 65536 (it multiplies 36 slots where 5 are non-zero)
+        self.fused_min_batch = 2048 if num_knots > 8 else 4096
+        self.mfma_min_batch = 32768 if num_knots > 8 else 4096
 
     def _fusable(self) -> bool:
         """rovit_kan_stack_fwd: up to 4 layers, widths after the input <= 64 and a multiple of 4 (or < 8)."""
@@ -72,7 +78,7 @@ class KANSeverityModule(nn.Module):
                 all(l.knots.numel() <= 64 for l in self.kan_layers))
 
     def _prepared(self):
-        """Per layer (spline_wt (in, nb, out), lin_wt (in, out)): the layouts rovit_kan_stack_fwd reads, rebuilt (one tiny
+        """Per layer (spline_wt (in, nb, out), lin_wt (in, out), wm = the rovit_kan_stack_fwd_mfma layout or None): rebuilt (one tiny
         launch per layer) whenever a parameter changed -- torch bumps ``_version`` on in-place updates; optimizers that
         write through flat buffers (RoViTAdamW) call ``invalidate_prepared()``."""
         key = tuple((p.data_ptr(), p._version) for l in self.kan_layers for p in (l.spline_weights, l.linear.weight))
@@ -84,7 +90,18 @@ class KANSeverityModule(nn.Module):
                 lwt = torch.empty(l.in_features, l.out_features, device=w.device, dtype=torch.float32)
                 native.call('rovit_kan_prepare', native.ptr(w), native.ptr(lw), native.ptr(wt), native.ptr(lwt), l.in_features,
                             l.out_features, l.num_basis, native.stream_ptr())
-                prep.append((wt, lwt))
+                nm = native.load().rovit_kan_mfma_prepared_floats(l.in_features, l.out_features, l.num_basis)
+                wm = None
+                # the matrix-core kernel computes interval indices arithmetically: uniform grids only (kan.py:59 builds
+                # the knots with torch.linspace; a non-uniform buffer could only come from a hand-edited state_dict)
+                kn = l.knots.detach().float().cpu()
+                hstep = float(kn[-1] - kn[0]) / (kn.numel() - 1)
+                uniform = bool(((kn[1:] - kn[:-1]) - hstep).abs().max() <= 1e-4 * abs(hstep))
+                if nm and uniform:
+                    wm = torch.empty(nm, device=w.device, dtype=torch.float32)
+                    native.call('rovit_kan_prepare_mfma', native.ptr(w), native.ptr(lw), native.ptr(wm), l.in_features, l.out_features,
+                                l.num_basis, native.stream_ptr())
+                prep.append((wt, lwt, wm))
             self._prep, self._prep_key = prep, key
         return self._prep
 
@@ -101,7 +118,10 @@ class KANSeverityModule(nn.Module):
             flat = []
             for layer in self.kan_layers:
                 flat += [layer.spline_weights, layer.knots, layer.linear.weight, layer.linear.bias]
-            return [x, *KANStackFn.apply(x, codes, self._prepared(), *flat)]
+            prep = self._prepared()
+            # from mfma_min_batch samples up the dense form on the matrix cores (rovit_kan_stack_fwd_mfma) is the faster one
+            mfma = x.shape[0] >= self.mfma_min_batch and all(p[2] is not None for p in prep)
+            return [x, *KANStackFn.apply(x, codes, prep, mfma, *flat)]
         acts = [x]
         for i, layer in enumerate(self.kan_layers):      # activation fused into the layer kernel
             x = layer._run(x, codes[i])

@@ -57,11 +57,12 @@ class KANLayerFn(torch.autograd.Function):
 class KANStackFn(torch.autograd.Function):
     """KANSeverityModule.forward (reference models/kan.py:138-149) as ONE launch (rovit_kan_stack_fwd); backward runs the
     per-layer kernels in reverse on the activations the fused forward wrote.
-    inputs: x, acts (tuple of ROVIT_ACT_*), prep (list of per-layer (spline_wt, lin_wt) prepared tensors), then per layer
-    (spline_w, knots, lin_w, lin_b); outputs: every layer's output."""
+    inputs: x, acts (tuple of ROVIT_ACT_*), prep (list of per-layer (spline_wt, lin_wt, wm) prepared tensors; wm = the
+    matrix-core layout or None), mfma (run rovit_kan_stack_fwd_mfma instead), then per layer (spline_w, knots, lin_w, lin_b);
+    outputs: every layer's output."""
 
     @staticmethod
-    def forward(ctx, x, acts, prep, *params):
+    def forward(ctx, x, acts, prep, mfma, *params):
         import ctypes as C
         x = _f32c(x)
         params = [_f32c(p) for p in params]
@@ -71,8 +72,12 @@ class KANStackFn(torch.autograd.Function):
         nks = [params[4 * l + 1].numel() for l in range(n)]
         outs = [torch.empty(B, dims[l + 1], device=x.device, dtype=torch.float32) for l in range(n)]
         arr = lambda xs: (C.c_int * len(xs))(*xs)
-        call('rovit_kan_stack_fwd', ptr(x), ptr_array([p[0] for p in prep]), ptr_array(params[1::4]), ptr_array([p[1] for p in prep]),
-             ptr_array(params[3::4]), ptr_array(outs), B, arr(dims), arr(nks), arr(list(acts)), n, stream_ptr())
+        if mfma:
+            call('rovit_kan_stack_fwd_mfma', ptr(x), ptr_array([p[2] for p in prep]), ptr_array(params[1::4]), ptr_array(params[3::4]),
+                 ptr_array(outs), B, arr(dims), arr(nks), arr(list(acts)), n, stream_ptr())
+        else:
+            call('rovit_kan_stack_fwd', ptr(x), ptr_array([p[0] for p in prep]), ptr_array(params[1::4]), ptr_array([p[1] for p in prep]),
+                 ptr_array(params[3::4]), ptr_array(outs), B, arr(dims), arr(nks), arr(list(acts)), n, stream_ptr())
         ctx.save_for_backward(x, *params, *outs)
         ctx.n, ctx.acts = n, tuple(acts)
         return tuple(outs)
@@ -95,7 +100,7 @@ class KANStackFn(torch.autograd.Function):
             w, knots, lw = params[4 * l], params[4 * l + 1], params[4 * l + 2]
             xin = x if l == 0 else outs[l - 1]
             need_dx = l > 0 or ctx.needs_input_grad[0]
-            need_dw = any(ctx.needs_input_grad[3 + 4 * l + k] for k in (0, 2, 3))
+            need_dw = any(ctx.needs_input_grad[4 + 4 * l + k] for k in (0, 2, 3))
             dx = torch.empty_like(xin) if need_dx else None
             dws = torch.empty_like(w) if need_dw else None
             dlw = torch.empty_like(lw) if need_dw else None
@@ -104,7 +109,7 @@ class KANStackFn(torch.autograd.Function):
                  ptr(dlb), xin.shape[0], xin.shape[1], lw.shape[0], knots.numel(), ctx.acts[l], 0, st)
             grads[4 * l], grads[4 * l + 2], grads[4 * l + 3] = dws, dlw, dlb
             g = dx
-        return (g if ctx.needs_input_grad[0] else None, None, None, *grads)
+        return (g if ctx.needs_input_grad[0] else None, None, None, None, *grads)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -466,6 +466,17 @@ def test_fused_kan_stack_forward_equals_per_layer_kernels_and_oracle(layers, num
     for k, p in m.named_parameters():
         assert float((p.grad.cpu() - rp[k].grad).abs().max()) < 5e-4 * float(rp[k].grad.abs().max() + 1e-6), k
     assert float((xd.grad.cpu() - xr.grad).abs().max()) < 5e-4 * float(xr.grad.abs().max())
+    # the matrix-core form of the same stack (rovit_kan_stack_fwd_mfma, used from mfma_min_batch samples up): same checks
+    if all(p[2] is not None for p in m._prepared()):
+        m.mfma_min_batch = 1
+        traj_m = m.get_activation_trajectory(x.to(dev()))
+        h = x.to(dev())
+        for i, layer in enumerate(m.kan_layers):
+            h = layer._run(traj_m[i], ACT_SIGMOID3 if i == len(m.kan_layers) - 1 else ACT_RELU)   # same inputs layer by layer
+            assert float((traj_m[i + 1] - h).abs().max()) < 2e-5, ('mfma', i)
+        assert float((traj_m[-1].cpu() - ref_cpu.kan_module_forward(x, sd)).abs().max()) < 1e-4
+    else:
+        assert layers[0] % 8 != 0              # the only parametrisation the matrix-core kernel does not cover
 
 
 def test_fp32_reference_precision_mode_meets_north_star_tolerances_end_to_end():

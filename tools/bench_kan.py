@@ -30,8 +30,11 @@ def kan_bytes(layers, nb, B, fused=True):
 
 def main():
     torch.manual_seed(0)
-    for name, layers, G, B in (('C3 head', [192, 64, 16, 1], 5, 256), ('C5 kan-heavy', [192, 64, 16, 1], 32, 512),
-                               ('streaming G=5', [192, 64, 16, 1], 5, 65536), ('streaming G=32', [192, 64, 16, 1], 32, 65536)):
+    shapes = (('C3 head', [192, 64, 16, 1], 5, 256), ('C5 kan-heavy', [192, 64, 16, 1], 32, 512),
+              ('streaming G=5', [192, 64, 16, 1], 5, 65536), ('streaming G=32', [192, 64, 16, 1], 32, 65536))
+    if '--sweep' in sys.argv:          # where the three forward kernels cross over
+        shapes = tuple((f'G={G} B={B}', [192, 64, 16, 1], G, B) for G in (5, 32) for B in (1024, 2048, 4096, 8192, 16384, 32768))
+    for name, layers, G, B in shapes:
         m = KANSeverityModule(layers, G, 3).to(dev)
         nb = G + 2
         x = torch.randn(B, layers[0], device=dev)
@@ -51,6 +54,15 @@ def main():
         sp = native.stream_ptr()
         xp = ptr(x)
         t_fused = timeit(lambda: lib.rovit_kan_stack_fwd(xp, a_w, a_k, a_lw, a_lb, a_o, B, dims, nks, acts, n, sp), 50)
+        t_mfma = None
+        if all(p[2] is not None for p in prep):
+            a_wm = ptr_array([p[2] for p in prep])
+            outs_m = [torch.empty_like(o) for o in outs]
+            a_om = ptr_array(outs_m)
+            t_mfma = timeit(lambda: lib.rovit_kan_stack_fwd_mfma(xp, a_wm, a_k, a_lb, a_om, B, dims, nks, acts, n, sp), 50)
+            lib.rovit_kan_stack_fwd(xp, a_w, a_k, a_lw, a_lb, a_o, B, dims, nks, acts, n, sp)
+            torch.cuda.synchronize()
+            mfma_err = [float((a - b).abs().max()) for a, b in zip(outs, outs_m)]
         ins = [x] + outs[:-1]
         raw = [(ptr(ins[i]), ptr(l.spline_weights), ptr(l.knots), ptr(l.linear.weight), ptr(l.linear.bias), ptr(outs[i]), l.in_features,
                 l.out_features, l.knots.numel(), ACT_SIGMOID3 if i == n - 1 else ACT_RELU) for i, l in enumerate(m.kan_layers)]
@@ -70,7 +82,10 @@ def main():
         print(json.dumps({'shape': name, 'layers': layers, 'num_knots': G, 'batch': B, 'fused_fwd_us': round(t_fused, 1),
                           'per_layer_fwd_us': round(t_layers, 1), 'fwd_bwd_us': round(t_fb, 1), 'algorithmic_bytes_fwd': alg,
                           'fused_fwd_GBps': round(alg / t_fused / 1e3, 1), 'per_layer_fwd_GBps': round(kan_bytes(layers, nb, B, False) / t_layers / 1e3, 1),
-                          'speedup_fwd': round(t_layers / t_fused, 2)}), flush=True)
+                          'speedup_fwd': round(t_layers / t_fused, 2),
+                          'mfma_fwd_us': None if t_mfma is None else round(t_mfma, 1),
+                          'mfma_fwd_GBps': None if t_mfma is None else round(alg / t_mfma / 1e3, 1),
+                          'mfma_vs_valu_max_abs_diff_per_layer': None if t_mfma is None else mfma_err}), flush=True)
 
 
 if __name__ == '__main__':

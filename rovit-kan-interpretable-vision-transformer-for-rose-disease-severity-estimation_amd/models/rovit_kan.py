@@ -53,6 +53,8 @@ class RoViTKAN(nn.Module):
 
     def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         stage = self._curriculum_stage
+        if x.shape[0] == 0:
+            return self._empty_outputs(x, stage)
         features = self.backbone(x)
         B, hid = features.shape[0], self.classification_head.fc1.out_features
         masks = None
@@ -76,6 +78,17 @@ class RoViTKAN(nn.Module):
             'log_var': log_var if stage >= 3 else None,
             'kan_severity': self.kan_module(features) if stage >= 4 else None,
         }
+
+    def _empty_outputs(self, x: torch.Tensor, stage: int) -> Dict[str, torch.Tensor]:
+        """An empty batch gives empty outputs of the right widths, as the reference's modules do (every op of
+        rovit_kan.py:88-124 accepts a zero-length batch dimension); no kernel is launched."""
+        from rovit_hip import native
+        native.ptr(x)                             # same device / dtype rules as a real batch (CPU tensors raise)
+        z = lambda w: torch.zeros(0, w, device=x.device, dtype=torch.float32)
+        return {'cls_logits': z(self.classification_head.fc2.out_features), 'features': z(self.backbone.embed_dim),
+                'ordinal_logits': z(self.ordinal_head.fc2.out_features) if stage >= 2 else None,
+                'mu': z(1) if stage >= 3 else None, 'log_var': z(1) if stage >= 3 else None,
+                'kan_severity': z(self.kan_module.layers_dims[-1]) if stage >= 4 else None}
 
     def predict(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         self.eval()

@@ -600,3 +600,69 @@ def test_data_parallel_world2_on_the_real_backward_gloo_over_one_gpu():
     cos = float(torch.nn.functional.cosine_similarity(res[0]['g'], g_ref, dim=0))
     print(f'world-2 averaged gradients vs single process: max |err| {err:.3e} (scale {scale:.3e}), cosine {cos:.7f}')
     assert err < 2e-3 * scale and cos > 0.99999
+
+
+def test_empty_batch_gives_empty_outputs_like_the_reference_modules():
+    """Every op of rovit_kan.py:88-124 accepts a zero-length batch; the drop-in returns empty outputs of the right widths
+    (no launch), keeps the None pattern of the stage gate, and still refuses CPU tensors."""
+    from rovit_hip.native import RovitHipError
+    m = _full_model(ref_cpu.init_rovit_state(seed=3)).eval()
+    x = torch.zeros(0, 3, 224, 224, device=dev())
+    for stage in (1, 2, 3, 4):
+        m.curriculum_stage = stage
+        with torch.no_grad():
+            out = m(x)
+        assert out['cls_logits'].shape == (0, 4) and out['features'].shape == (0, 192)
+        assert (out['ordinal_logits'] is None) == (stage < 2) and (out['mu'] is None) == (stage < 3)
+        assert (out['kan_severity'] is None) == (stage < 4)
+        if stage == 4:
+            assert out['ordinal_logits'].shape == (0, 3) and out['mu'].shape == (0, 1) and out['kan_severity'].shape == (0, 1)
+    with pytest.raises(RovitHipError):
+        m(torch.zeros(0, 3, 224, 224))
+    p = m.predict(x)
+    assert p['class'].shape == (0,) and p['class_probs'].shape == (0, 4)
+
+
+@pytest.mark.parametrize('B', [1, 5, 67])
+def test_ragged_batches_full_model_forward_and_backward_vs_oracle(B):
+    """Batch sizes that fill no tile of any kernel (1 image = 197 rows; 5; 67 = 13 199 rows: partial 32/64-row GEMM tiles,
+    a partial last M-split of the weight-gradient launch, a half-empty two-stream split): every output and every
+    parameter gradient of the full model against the oracle's autograd, heads/KAN evaluated at the HIP path's features."""
+    depth = 12 if B <= 5 else 2
+    sd = ref_cpu.init_rovit_state(depth=depth, seed=40 + B)
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, 3, 224, 224, generator=g)
+    y = torch.randint(0, 4, (B,), generator=g)
+    from models.rovit_kan import RoViTKAN
+    from models.backbone import DeiTTiny
+    m = RoViTKAN(pretrained=False)
+    if depth != 12:
+        m.backbone.model = DeiTTiny(depth=depth)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev()).eval()
+    out = m(x.to(dev()))
+    w = {k: torch.randn(out[k].shape, generator=g) for k in ('cls_logits', 'ordinal_logits', 'mu', 'log_var', 'kan_severity')}
+    sum((out[k] * w[k].to(dev())).sum() for k in w).backward()
+    # oracle: backbone by autograd; heads and KAN at the HIP path's own features (the spline is discontinuous, DESIGN.md 2)
+    rp = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and 'knots' not in k else v) for k, v in sd.items()}
+    feats = ref_cpu.vit_forward(x, rp, prefix='backbone.model.')
+    assert float((out['features'].detach().cpu() - feats.detach()).abs().max()) < BF16_TOL
+    f_hip = out['features'].detach().cpu().requires_grad_(True)
+    ho = ref_cpu.heads_forward(f_hip, rp, 4)
+    ho['kan_severity'] = ref_cpu.kan_module_forward(f_hip, rp, 'kan_module.')
+    for k in w:
+        assert float((out[k].detach().cpu() - ho[k].detach()).abs().max()) < 1e-3, k        # fp32 heads / KAN: north_star's 1e-3
+    sum((ho[k] * w[k]).sum() for k in w).backward()
+    feats.backward(f_hip.grad)
+    worst = 0.0
+    for k, p in m.named_parameters():
+        ref, got = rp[k].grad, p.grad.cpu()
+        scale = float(ref.abs().max().clamp_min(1e-8))
+        rel = float((got - ref).abs().max()) / scale
+        if k.startswith('backbone'):
+            cos = float(torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0))
+            assert cos > 0.999 and rel < 6e-2, (k, cos, rel)
+        else:
+            assert rel < 1e-3, (k, rel)
+        worst = max(worst, rel)
+    print(f'B={B} depth={depth}: worst relative gradient error {worst:.3e}')

@@ -15,7 +15,7 @@ def dropout_mask(drop: nn.Dropout, training: bool, shape, device) -> Optional[to
     if not training or drop.p <= 0.0:
         return None
     keep = 1.0 - drop.p
-    return (torch.rand(shape, device=device) < keep).float().div_(keep)
+    return torch.empty(shape, device=device, dtype=torch.float32).bernoulli_(keep).mul_(1.0 / keep)      # two launches
 
 
 class _Head(nn.Module):

@@ -64,7 +64,7 @@ class RoViTKAN(nn.Module):
             ps = {h.dropout.p for (h, _), a in zip(heads, live) if a}
             if len(ps) == 1:                      # one random draw for all active heads (3 launches instead of 9-12)
                 keep = 1.0 - ps.pop()
-                m = (torch.rand(sum(live), B, hid, device=features.device) < keep).float().div_(keep)
+                m = torch.empty(sum(live), B, hid, device=features.device).bernoulli_(keep).mul_(1.0 / keep)
                 it = iter(m.unbind(0))
                 masks = [next(it) if a else None for a in live]
             elif ps:

@@ -55,7 +55,6 @@ def _event_avg_ms(dev, run, iters, per_launch=True):
     EVERY launch with its own pair of events (a kernel's whole life, first workgroup in to last workgroup out -- what
     rocprofv3 --kernel-trace reports per dispatch); per_launch=False times the back-to-back train, where one launch's
     ramp hides in the previous launch's tail (throughput view; 10-18 % shorter for these 20-100 us kernels)."""
-    _warm_clocks(dev)
     for _ in range(5):
         run()
     st = torch.cuda.current_stream(dev)
@@ -106,6 +105,7 @@ def wgrad_roofline(dev, iters=30):
 
     def run():
         native.call('rovit_wgrad_multi', a_dy, ldy, a_a, lda, Ns, Ks, a_ws, 4, M, splits, native.stream_ptr())
+    _warm_clocks(dev)
     ms = _event_avg_ms(dev, run, iters)
     ms_train = _event_avg_ms(dev, run, iters, per_launch=False)
     flops = sum(2.0 * M * n * k for n, k in shapes)
@@ -146,6 +146,7 @@ def gemm_roofline(dev, iters=30):
     def run():
         native.call('rovit_gemm_nt', native.ptr(A), K, native.ptr(W), K, M, N, K, native.ptr(bias), 1, native.ptr(out), N,
                     native.ptr(out2), None, 0, None, 0, None, 0, native.stream_ptr())
+    _warm_clocks(dev)
     ms = _event_avg_ms(dev, run, iters)
     flops = 2.0 * M * N * K
     # algorithmic bytes per launch: read xhat (M*K) + W (N*K), write act + dact (2*M*N), all bf16
@@ -171,6 +172,7 @@ def kan_roofline(dev, iters=30):
     lib = native.load()
     layers = [192, 64, 16, 1]
     res = {}
+    _warm_clocks(dev)
     for key, G, B in (('c5_g32_b512', 32, 512), ('stream_g5_b65536', 5, 65536), ('stream_g32_b65536', 32, 65536), ('c3_g5_b256', 5, 256)):
         m = KANSeverityModule(layers, G, 3).to(dev)
         nb, n = G + 2, 3

@@ -75,7 +75,7 @@ __device__ __forceinline__ float act_grad(float g, float y, int act) {
 // forward: one workgroup = TB samples.  Phase 1: per (sample, feature) tanh + grid lookup -> LDS.
 // Phase 2: thread = (sample, output): 4 FMAs against the W[i, o, j-3..j] slab + the linear term.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void kan_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+__global__ __launch_bounds__(1024) void kan_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                       const float* __restrict__ knots, const float* __restrict__ lw,
                                                       const float* __restrict__ lb, float* __restrict__ out, int B,
                                                       int in_f, int out_f, int nk, int TB, int act) {
@@ -84,13 +84,13 @@ __global__ __launch_bounds__(256) void kan_fwd_kernel(const float* __restrict__ 
   float* s_x = s_knots + KAN_MAX_KNOTS;
   float* s_v = s_x + TB * in_f;
   int* s_j = (int*)(s_v + 4 * TB * in_f);
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, T = blockDim.x;
   const int nb = nk - 4;
   const int b0 = blockIdx.x * TB;
   if (tid < nk) s_knots[tid] = knots[tid];
   __syncthreads();
   const float inv_h0 = 1.f / (s_knots[1] - s_knots[0]);
-  for (int e = tid; e < TB * in_f; e += 256) {
+  for (int e = tid; e < TB * in_f; e += T) {
     const int bl = e / in_f, i = e - bl * in_f, b = b0 + bl;
     float xv = 0.f;
     Basis4 bs; bs.j = -1; bs.v[0] = bs.v[1] = bs.v[2] = bs.v[3] = 0.f;
@@ -105,11 +105,12 @@ __global__ __launch_bounds__(256) void kan_fwd_kernel(const float* __restrict__ 
   __syncthreads();
   // Contraction.  The (sample, output) items of this workgroup are few (<= 64 for the layer shapes of this
   // model), so each item is shared by `nsplit` threads that each walk a slice of the input features (the loop is a
-  // chain of dependent L2 gathers; one thread per item left 3 of 4 waves idle and took ~30 us per layer).
-  float* s_part = (float*)(s_j + TB * in_f);            // [256] partial sums
+  // chain of dependent L2 gathers: its length sets the time.  1024 threads give 16 slices of 12 features for the 192 -> 64
+  // layer at one sample per workgroup: 28 -> 14 us at batch 256).
+  float* s_part = (float*)(s_j + TB * in_f);            // [T] partial sums
   const int items = TB * out_f;
-  const int nsplit = items >= 256 ? 1 : 256 / items;
-  for (int e0 = 0; e0 < items; e0 += 256) {
+  const int nsplit = items >= T ? 1 : T / items;
+  for (int e0 = 0; e0 < items; e0 += T) {
     const int e = e0 + (nsplit == 1 ? tid : tid % items);
     const int part = nsplit == 1 ? 0 : tid / items;
     float acc = 0.f;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void kan_fwd_kernel(const float* __restrict__ 
 }
 
 // backward wrt the layer input: thread = (sample, feature)
-__global__ __launch_bounds__(256) void kan_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ W,
+__global__ __launch_bounds__(1024) void kan_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                          const float* __restrict__ knots, const float* __restrict__ lw,
                                                          const float* __restrict__ y, const float* __restrict__ gy,
                                                          float* __restrict__ dx, int B, int in_f, int out_f, int nk,
@@ -160,20 +161,25 @@ __global__ __launch_bounds__(256) void kan_bwd_dx_kernel(const float* __restrict
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_knots = smem;
   float* s_g = s_knots + KAN_MAX_KNOTS;      // TB * out_f : dL/dz
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, T = blockDim.x;
   const int nb = nk - 4;
   const int b0 = blockIdx.x * TB;
   if (tid < nk) s_knots[tid] = knots[tid];
-  for (int e = tid; e < TB * out_f; e += 256) {
+  for (int e = tid; e < TB * out_f; e += T) {
     const int bl = e / out_f, b = b0 + bl;
     s_g[e] = b < B ? act_grad(gy[(size_t)b0 * out_f + e], y[(size_t)b0 * out_f + e], act) : 0.f;
   }
   __syncthreads();
   const float inv_h0 = 1.f / (s_knots[1] - s_knots[0]);
-  for (int e = tid; e < TB * in_f; e += 256) {
-    const int bl = e / in_f, i = e - bl * in_f, b = b0 + bl;
-    if (b >= B) continue;
-    const float xv = x[(size_t)b * in_f + i];
+  // four adjacent lanes share one (sample, feature): each walks a quarter of the outputs (a chain of L2 gathers whose
+  // length sets the time), the partial sums meet through two cross-lane adds
+  const int part = tid & 3;
+  for (int e0 = 0; e0 < TB * in_f; e0 += T / 4) {
+    const int e = e0 + (tid >> 2);
+    const bool live = e < TB * in_f && b0 + e / in_f < B;
+    const int ec = live ? e : 0;
+    const int bl = ec / in_f, i = ec - bl * in_f, b = b0 + bl;
+    const float xv = x[(size_t)(b < B ? b : B - 1) * in_f + i];
     const float xn = tanhf(xv);
     float dv[4];
     const Basis4 bs = kan_basis<true>(xn, s_knots, nk, inv_h0, dv);
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(256) void kan_bwd_dx_kernel(const float* __restrict
     const int j1 = jc >= 1 ? jc - 1 : 0, j2 = jc >= 2 ? jc - 2 : 0, j3 = jc >= 3 ? jc - 3 : 0;
     const float d0 = bs.j >= 0 ? dv[0] : 0.f, d1 = bs.j >= 1 ? dv[1] : 0.f, d2 = bs.j >= 2 ? dv[2] : 0.f, d3 = bs.j >= 3 ? dv[3] : 0.f;
 #pragma unroll 8
-    for (int o = 0; o < out_f; ++o) {                     // branch-free: loads of several outputs in flight
+    for (int o = part; o < out_f; o += 4) {               // branch-free: loads of several outputs in flight
       const float go = g[o];
       const float* w = W + ((size_t)i * out_f + o) * nb;
       const float w0 = w[jc], w1 = w[j1], w2 = w[j2], w3 = w[j3];
@@ -194,9 +200,13 @@ __global__ __launch_bounds__(256) void kan_bwd_dx_kernel(const float* __restrict
       sv = fmaf(d3, w3, sv);
       spl = fmaf(go, sv, spl);
     }
-    const float r = fmaf(spl, 1.f - xn * xn, lin);       // d tanh; clamp is the identity on (-1, 1)
-    float* p = dx + (size_t)b * in_f + i;
-    *p = accumulate ? *p + r : r;
+    lin += __shfl_xor(lin, 1); spl += __shfl_xor(spl, 1);
+    lin += __shfl_xor(lin, 2); spl += __shfl_xor(spl, 2);
+    if (live && part == 0) {
+      const float r = fmaf(spl, 1.f - xn * xn, lin);       // d tanh; clamp is the identity on (-1, 1)
+      float* p = dx + (size_t)b * in_f + i;
+      *p = accumulate ? *p + r : r;
+    }
   }
 }
 
@@ -391,20 +401,29 @@ struct LinFwdDesc { const float* x; const float* w; const float* bias; const flo
 struct LinFwdBatch { LinFwdDesc d[4]; int first[5]; int n, B; };
 
 __global__ __launch_bounds__(256) void lin_fwd_batch_kernel(const LinFwdBatch pb) {
+  // four lanes per output element, each walking a quarter of the input features with 16-byte loads (in_f = 192: twelve
+  // loads per lane, all in flight together), combined with two cross-lane adds: the dot product is a latency chain, not work
   int i = 0;
   while (i + 1 < pb.n && (int)blockIdx.x >= pb.first[i + 1]) ++i;
   const LinFwdDesc& d = pb.d[i];
-  const int e = ((int)blockIdx.x - pb.first[i]) * 256 + threadIdx.x;
-  if (e >= pb.B * d.out_f) return;
-  const int b = e / d.out_f, o = e - b * d.out_f;
+  const int t = ((int)blockIdx.x - pb.first[i]) * 256 + threadIdx.x;
+  const int e = t >> 2, part = t & 3;
+  const bool live = e < pb.B * d.out_f;
+  const int ec = live ? e : 0;
+  const int b = ec / d.out_f, o = ec - b * d.out_f;
   const float4* xr = (const float4*)(d.x + (size_t)b * d.in_f);
   const float4* wr = (const float4*)(d.w + (size_t)o * d.in_f);
-  float acc = d.bias ? d.bias[o] : 0.f;
+  const int n4 = d.in_f / 4;
+  float acc = 0.f;
 #pragma unroll 12
-  for (int k = 0; k < d.in_f / 4; ++k) {
+  for (int k = part; k < n4; k += 4) {
     const float4 a = xr[k], c = wr[k];
     acc = fmaf(a.x, c.x, acc); acc = fmaf(a.y, c.y, acc); acc = fmaf(a.z, c.z, acc); acc = fmaf(a.w, c.w, acc);
   }
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  if (!live || part != 0) return;
+  if (d.bias) acc += d.bias[o];
   if (d.flags & ROVIT_LIN_RELU) acc = fmaxf(acc, 0.f);
   if (d.mask) acc *= d.mask[e];
   if (d.flags & ROVIT_LIN_CLAMP10) acc = fminf(fmaxf(acc, -10.f), 10.f);
@@ -442,18 +461,18 @@ struct LinDwBatch { LinDwDesc d[4]; int first[5]; int n, B; };
 // One workgroup = 64 consecutive dW elements x 4 batch slices (wave w sums samples w, w+4, ...), partial sums
 // combined through LDS: the sample loop is a chain of dependent global loads, so its length, not the arithmetic, sets
 // the kernel time (62 us with one thread walking all 256 samples).
-__global__ __launch_bounds__(256) void lin_bwd_dw_batch_kernel(const LinDwBatch pb) {
-  __shared__ float s_w[4][64], s_b[4][64];
+__global__ __launch_bounds__(1024) void lin_bwd_dw_batch_kernel(const LinDwBatch pb) {
+  __shared__ float s_w[16][64], s_b[16][64];
   int i = 0;
   while (i + 1 < pb.n && (int)blockIdx.x >= pb.first[i + 1]) ++i;
   const LinDwDesc& d = pb.d[i];
-  const int el = threadIdx.x & 63, bs = threadIdx.x >> 6;
+  const int el = threadIdx.x & 63, bs = threadIdx.x >> 6;          // 16 batch slices: 16 samples per thread at batch 256
   const int e = ((int)blockIdx.x - pb.first[i]) * 64 + el;
   const bool live = e < d.out_f * d.in_f;
   const int o = live ? e / d.in_f : 0, k = live ? e - o * d.in_f : 0;
   float acc = 0.f, accb = 0.f;
 #pragma unroll 16
-  for (int b = bs; b < pb.B; b += 4) {
+  for (int b = bs; b < pb.B; b += 16) {
     const size_t q = (size_t)b * d.out_f + o;
     const float gv = clamp_gate(d.g[q], d.yc, q);
     acc = fmaf(gv, d.x[(size_t)b * d.in_f + k], acc);
@@ -462,18 +481,21 @@ __global__ __launch_bounds__(256) void lin_bwd_dw_batch_kernel(const LinDwBatch 
   s_w[bs][el] = acc; s_b[bs][el] = accb;
   __syncthreads();
   if (bs == 0 && live) {
-    d.dw[e] = (s_w[0][el] + s_w[1][el]) + (s_w[2][el] + s_w[3][el]);
-    if (k == 0) d.db[o] = (s_b[0][el] + s_b[1][el]) + (s_b[2][el] + s_b[3][el]);
+    float tw = 0.f, tb = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { tw += s_w[q][el]; tb += s_b[q][el]; }
+    d.dw[e] = tw;
+    if (k == 0) d.db[o] = tb;
   }
 }
 
 template <class Batch, class Kernel>
-int launch_lin_batch(Batch& pb, int n, const int* work, Kernel kern, const char* name, hipStream_t st, int per_block = 256) {
+int launch_lin_batch(Batch& pb, int n, const int* work, Kernel kern, const char* name, hipStream_t st, int per_block = 256, int threads = 256) {
   int blocks = 0;
   for (int i = 0; i < n; ++i) { pb.first[i] = blocks; blocks += (work[i] + per_block - 1) / per_block; }
   pb.first[n] = blocks; pb.n = n;
   if (blocks == 0) return ROVIT_OK;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st, pb);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, st, pb);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { rovit_set_error("%s: launch failed: %s", name, hipGetErrorString(e)); return ROVIT_ERR_LAUNCH; }
   return ROVIT_OK;
@@ -499,9 +521,10 @@ extern "C" int rovit_kan_layer_fwd(const float* x, const float* spline_w, const 
   ROVIT_CHECK_ARG(n_knots >= 8 && n_knots <= KAN_MAX_KNOTS, ROVIT_ERR_SHAPE,
                   "kan_layer_fwd: degree-3 layer needs 8..%d knots, got %d", KAN_MAX_KNOTS, n_knots);
   const int tb = kan_tb(out_f);
-  const size_t lds = (KAN_MAX_KNOTS + (size_t)tb * in_f * 6 + 256) * sizeof(float);
+  const int threads = (tb * out_f <= 64 && in_f >= 32) ? 1024 : 256;       // more feature slices per (sample, output) item
+  const size_t lds = (KAN_MAX_KNOTS + (size_t)tb * in_f * 6 + threads) * sizeof(float);
   ROVIT_CHECK_ARG(lds <= 64 * 1024, ROVIT_ERR_SHAPE, "kan_layer_fwd: in_features %d too large for the LDS tile", in_f);
-  hipLaunchKernelGGL(kan_fwd_kernel, dim3((batch + tb - 1) / tb), dim3(256), lds, (hipStream_t)stream, x, spline_w, knots,
+  hipLaunchKernelGGL(kan_fwd_kernel, dim3((batch + tb - 1) / tb), dim3(threads), lds, (hipStream_t)stream, x, spline_w, knots,
                      lin_w, lin_b, out, batch, in_f, out_f, n_knots, tb, act);
   ROVIT_CHECK_LAUNCH("kan_fwd_kernel");
   return ROVIT_OK;
@@ -517,7 +540,7 @@ extern "C" int rovit_kan_layer_bwd(const float* x, const float* spline_w, const 
   if (dx) {
     const int tb = kan_tb(out_f);
     const size_t lds = (KAN_MAX_KNOTS + (size_t)tb * out_f) * sizeof(float);
-    hipLaunchKernelGGL(kan_bwd_dx_kernel, dim3((batch + tb - 1) / tb), dim3(256), lds, (hipStream_t)stream, x, spline_w,
+    hipLaunchKernelGGL(kan_bwd_dx_kernel, dim3((batch + tb - 1) / tb), dim3(tb * in_f * 4 >= 1024 ? 1024 : 256), lds, (hipStream_t)stream, x, spline_w,
                        knots, lin_w, out, grad_out, dx, batch, in_f, out_f, n_knots, tb, act, accumulate_dx);
     ROVIT_CHECK_LAUNCH("kan_bwd_dx_kernel");
   }
@@ -591,7 +614,7 @@ extern "C" int rovit_heads_fwd(const float* features, const float* const* params
     f1.d[h] = {features, params[4 * h], params[4 * h + 1], masks ? masks[h] : nullptr, hidden + h * hs, embed, hid, ROVIT_LIN_RELU};
     work[h] = batch * hid;
   }
-  int rc = launch_lin_batch(f1, nheads, work, lin_fwd_batch_kernel, "lin_fwd_batch_kernel", (hipStream_t)stream);
+  int rc = launch_lin_batch(f1, nheads, work, lin_fwd_batch_kernel, "lin_fwd_batch_kernel", (hipStream_t)stream, 64);
   if (rc) return rc;
   LinFwdBatch f2{}; f2.B = batch;
   int n = 0;
@@ -601,7 +624,7 @@ extern "C" int rovit_heads_fwd(const float* features, const float* const* params
     f2.d[n] = {hidden + 2 * hs, params[10], params[11], nullptr, mu, hid, 1, 0}; work[n++] = batch;
     f2.d[n] = {hidden + 2 * hs, params[12], params[13], nullptr, log_var, hid, 1, ROVIT_LIN_CLAMP10}; work[n++] = batch;
   }
-  return launch_lin_batch(f2, n, work, lin_fwd_batch_kernel, "lin_fwd_batch_kernel", (hipStream_t)stream);
+  return launch_lin_batch(f2, n, work, lin_fwd_batch_kernel, "lin_fwd_batch_kernel", (hipStream_t)stream, 64);
 }
 
 // grads[] mirrors params[]; g_* may be NULL (head inactive or output unused); log_var is the clamped forward output.
@@ -644,7 +667,7 @@ extern "C" int rovit_heads_bwd(const float* features, const float* const* params
   }
   int rc = launch_lin_batch(dxh, nx, wx, lin_bwd_dx_batch_kernel, "lin_bwd_dx_batch_kernel", st);
   if (rc) return rc;
-  rc = launch_lin_batch(dwo, nw, ww, lin_bwd_dw_batch_kernel, "lin_bwd_dw_batch_kernel", st, 64);
+  rc = launch_lin_batch(dwo, nw, ww, lin_bwd_dw_batch_kernel, "lin_bwd_dw_batch_kernel", st, 64, 1024);
   if (rc) return rc;
   // 2) through the first layers: d_features = sum_h dh_h W1_h ; dW1_h = dh_h^T features
   LinDxBatch dxf{}; dxf.B = batch;
@@ -661,5 +684,5 @@ extern "C" int rovit_heads_bwd(const float* features, const float* const* params
   int wf[1] = {batch * embed};
   rc = launch_lin_batch(dxf, 1, wf, lin_bwd_dx_batch_kernel, "lin_bwd_dx_batch_kernel", st);
   if (rc) return rc;
-  return launch_lin_batch(dw1, n1, w1, lin_bwd_dw_batch_kernel, "lin_bwd_dw_batch_kernel", st, 64);
+  return launch_lin_batch(dw1, n1, w1, lin_bwd_dw_batch_kernel, "lin_bwd_dw_batch_kernel", st, 64, 1024);
 }

@@ -279,19 +279,27 @@ int vit_forward_impl(const float* images, const float* const* params, const void
 #define ROWS(ptr, width, esz) ((ptr) + (size_t)h.b0 * T * (width) * (esz))
     // LayerNorm1 of block 0 is a kernel of its own; every other LayerNorm of the loop is fused into the epilogue
     // of the GEMM that produces its input (proj -> norm2, fc2 -> next block's norm1).
-    if (i == 0) EACH_HALF {
-      const Half& h = halves[hh];
-      RUN(rovit_layernorm_fwd(X + (size_t)h.b0 * T * D, ROWS(s + L.xhat1, D, 2), (float*)ROWS(s + L.rstd1, 1, 4), h.nb * T, D, eps, h.st));
-    }
-    EACH_HALF {
-      const Half& h = halves[hh];
-      RUN(rovit_gemm_nt(ROWS(s + L.xhat1, D, 2), D, q + P.wqkv, D, h.nb * T, 3 * D, D, (const float*)(q + P.bqkv), EPI_BF16,
-                        ROWS(s + L.qkv, 3 * D, 2), 3 * D, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, h.st));
-    }
-    EACH_HALF {
-      const Half& h = halves[hh];
-      RUN(rovit_attention_fwd(ROWS(s + L.qkv, 3 * D, 2), ROWS(s + L.o, D, 2), (float*)(s + L.lse) + (size_t)h.b0 * H * T, h.nb, T, H, D / H,
-                              0.125f, h.st));
+    // Stagger (ROVIT_FWD_STAGGER=1): the second half starts after the first half's attention of block 0, so that from then on
+    // an attention kernel (LDS/MFMA-bound) of one half runs beside a GEMM (HBM-bound) of the other instead of beside its twin.
+    static const bool stagger = getenv("ROVIT_FWD_STAGGER") && getenv("ROVIT_FWD_STAGGER")[0] == '1';
+    const bool stag0 = stagger && ss && i == 0;
+    for (int pass = 0; pass < (stag0 ? 2 : 1); ++pass) {
+      const int h_lo = stag0 ? pass : 0, h_hi = stag0 ? pass + 1 : nh;
+      if (stag0 && pass == 1 && !hand_over(ss, (hipStream_t)stream, ss->stream)) { rovit_set_error("vit_forward: event hand-over failed"); return ROVIT_ERR_LAUNCH; }
+      if (i == 0) for (int hh = h_lo; hh < h_hi; ++hh) {
+        const Half& h = halves[hh];
+        RUN(rovit_layernorm_fwd(X + (size_t)h.b0 * T * D, ROWS(s + L.xhat1, D, 2), (float*)ROWS(s + L.rstd1, 1, 4), h.nb * T, D, eps, h.st));
+      }
+      for (int hh = h_lo; hh < h_hi; ++hh) {
+        const Half& h = halves[hh];
+        RUN(rovit_gemm_nt(ROWS(s + L.xhat1, D, 2), D, q + P.wqkv, D, h.nb * T, 3 * D, D, (const float*)(q + P.bqkv), EPI_BF16,
+                          ROWS(s + L.qkv, 3 * D, 2), 3 * D, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, h.st));
+      }
+      for (int hh = h_lo; hh < h_hi; ++hh) {
+        const Half& h = halves[hh];
+        RUN(rovit_attention_fwd(ROWS(s + L.qkv, 3 * D, 2), ROWS(s + L.o, D, 2), (float*)(s + L.lse) + (size_t)h.b0 * H * T, h.nb, T, H, D / H,
+                                0.125f, h.st));
+      }
     }
     // explainability tap: the attention module's output (proj(attention) + bias, before the residual add) for
     // every token of block i -- what a forward hook on `blocks[i].attn` sees (reference models/backbone.py:37-62)

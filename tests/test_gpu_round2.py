@@ -448,11 +448,14 @@ def test_fused_kan_stack_forward_equals_per_layer_kernels_and_oracle(layers, num
     assert m._fusable()
     m.fused_min_batch = 1                      # force the one-launch path at every batch size
     traj = m.get_activation_trajectory(x.to(dev()))
-    # per-layer kernels
+    # per-layer kernels: layer by layer on the SAME inputs to 2e-5 (fp32 summation order), and cascaded from x to 1e-4 (at
+    # G = 32 a 1e-6 difference in a layer input moves the next layer's basis by 1e-6 / h = 2e-5 per term)
     h = x.to(dev())
     for i, layer in enumerate(m.kan_layers):
-        h = layer._run(h, ACT_SIGMOID3 if i == len(m.kan_layers) - 1 else ACT_RELU)
-        assert float((traj[i + 1] - h).abs().max()) < 2e-5, i
+        code = ACT_SIGMOID3 if i == len(m.kan_layers) - 1 else ACT_RELU
+        assert float((traj[i + 1] - layer._run(traj[i], code)).abs().max()) < 2e-5, i
+        h = layer._run(h, code)
+        assert float((traj[i + 1] - h).abs().max()) < 1e-4, i
     ref_in = ref_cpu.kan_module_layer_inputs(x, sd)
     for i in range(1, len(ref_in)):
         assert float((traj[i].cpu() - ref_in[i]).abs().max()) < 1e-4, i

@@ -17,12 +17,23 @@ images = torch.randn(256, 3, 224, 224, device=dev)
 labels = torch.randint(0, 4, (256,), device=dev)
 names = ['backbone fwd', 'heads+kan fwd', 'loss', 'heads+kan bwd + backbone bwd', 'optimizer']
 N = 20
-ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(N)]
+ev = [[torch.cuda.Event(enable_timing=True) for _ in range(8)] for _ in range(N)]
+cur = {'e': None}
 host = [[0.0] * 6 for _ in range(N)]
 st = torch.cuda.current_stream()
 
 
+def _after_backbone(mod, inp, outp):
+    cur['e'][6].record(st)                                 # backbone forward enqueued
+    if outp.requires_grad:
+        outp.register_hook(lambda g: cur['e'][7].record(st))   # gradient w.r.t. the features is ready: heads/KAN backward done
+
+
+model.backbone.register_forward_hook(_after_backbone)
+
+
 def run(e, h):
+    cur['e'] = e
     e[0].record(st); h[0] = time.perf_counter()
     out = model(images)
     e[2].record(st); h[2] = time.perf_counter()
@@ -48,5 +59,8 @@ for name, a, b in seg:
     g = sum(ev[i][a].elapsed_time(ev[i][b]) for i in range(3, N)) / (N - 3)
     hh = sum(host[i][b] - host[i][a] for i in range(3, N)) / (N - 3) * 1e3
     print(f'{name:42s} device {g:7.3f} ms   host enqueue {hh:7.3f} ms')
+for name, a, b in (('  backbone forward', 0, 6), ('  heads + KAN forward', 6, 2), ('  heads + KAN backward', 3, 7), ('  backbone backward', 7, 4)):
+    g = sum(ev[i][a].elapsed_time(ev[i][b]) for i in range(3, N)) / (N - 3)
+    print(f'{name:42s} device {g:7.3f} ms')
 g = sum(ev[i][5].elapsed_time(ev[i + 1][0]) for i in range(3, N - 1)) / (N - 4)
 print(f'{"between steps":42s} device {g:7.3f} ms')

@@ -521,7 +521,10 @@ extern "C" int rovit_kan_layer_fwd(const float* x, const float* spline_w, const 
   ROVIT_CHECK_ARG(n_knots >= 8 && n_knots <= KAN_MAX_KNOTS, ROVIT_ERR_SHAPE,
                   "kan_layer_fwd: degree-3 layer needs 8..%d knots, got %d", KAN_MAX_KNOTS, n_knots);
   const int tb = kan_tb(out_f);
-  const int threads = (tb * out_f <= 64 && in_f >= 32) ? 1024 : 256;       // more feature slices per (sample, output) item
+  // more feature slices per (sample, output) item -- for short basis rows only: at num_knots 32 (136-byte rows, one cache line
+  // per gathered (feature, output) pair) four times the threads only add L2 pressure (C5: 51 -> 84 us, measured)
+  // ... and for batches that do not fill the chip with 256-thread workgroups anyway (batch 65536: 2.35 -> 3.33 ms with 1024)
+  const int threads = (tb * out_f <= 64 && in_f >= 32 && n_knots <= 16 && batch <= 1024) ? 1024 : 256;
   const size_t lds = (KAN_MAX_KNOTS + (size_t)tb * in_f * 6 + threads) * sizeof(float);
   ROVIT_CHECK_ARG(lds <= 64 * 1024, ROVIT_ERR_SHAPE, "kan_layer_fwd: in_features %d too large for the LDS tile", in_f);
   hipLaunchKernelGGL(kan_fwd_kernel, dim3((batch + tb - 1) / tb), dim3(threads), lds, (hipStream_t)stream, x, spline_w, knots,

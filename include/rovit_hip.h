@@ -125,7 +125,9 @@ int rovit_vit_forward(const float* images, const float* const* params, const voi
  * probabilities per block, what explainability/attention_maps.py:18-105 means to roll out.  Inference workspace. */
 int rovit_vit_forward_taps(const float* images, const float* const* params, const void* prep, void* workspace, float* features,
                            void* const* attn_taps, float* const* prob_taps, int batch, int depth, rovit_stream_t stream);
-int rovit_vit_backward(const float* d_features, const float* const* params, const void* prep, void* workspace,
+/* images: the batch the forward ran on (read by the patch-embedding weight gradient, which gathers its pixels from it:
+ * there is no im2col buffer); may be NULL for ranges with last_block > 0. */
+int rovit_vit_backward(const float* images, const float* d_features, const float* const* params, const void* prep, void* workspace,
                        float* const* grads, int batch, int depth, int first_block, int last_block, rovit_stream_t stream);
 /* fp32 reference-precision forward (inference only; parity / evaluation mode, not the fast path): the same arithmetic
  * with every operand, product and sum in fp32 -- the mode in which BASELINE.json's "logits/severity within 1e-3 (fp32),
@@ -148,8 +150,8 @@ int rovit_vit_workspace_field(int batch, int depth, int field, int block, size_t
 /* rovit_vit_backward for a data-parallel caller: for last_block > 0 the call does not wait for the range's weight
  * gradients on `stream`; `notify_stream` (the caller's reduction stream) is made to wait for them instead.  Issue the
  * ranges in order down to last_block == 0; that call joins everything into `stream`. */
-int rovit_vit_backward_notify(const float* d_features, const float* const* params, const void* prep, void* workspace,
-                              float* const* grads, int batch, int depth, int first_block, int last_block,
+int rovit_vit_backward_notify(const float* images, const float* d_features, const float* const* params, const void* prep,
+                              void* workspace, float* const* grads, int batch, int depth, int first_block, int last_block,
                               rovit_stream_t stream, rovit_stream_t notify_stream);
 
 /* ---- the individual backbone kernels (used by rovit_vit_* and exposed for unit tests / profiling) ---------- */
@@ -206,6 +208,15 @@ int rovit_layernorm_fwd(const float* x, void* xhat, float* rstd, int rows, int d
 int rovit_layernorm_bwd(const void* dxhat, const void* xhat, const float* rstd, float* dX, void* dXb, int rows, int dim,
                         rovit_stream_t stream);
 int rovit_im2col(const float* x, void* col, int batch, rovit_stream_t stream);
+/* PatchEmbed (timm conv k16 s16, reached through models/backbone.py:12-25) without the im2col buffer: the GEMM and the
+ * weight-gradient kernel gather their pixel operand from the fp32 NCHW images and round it to bf16 on the way into LDS.
+ *   fwd:   X[b*tokens + 1 + p][:] = patch(b, p) W^T + bias + pos[1 + p]      (W bf16 (192,768), X fp32 (batch*tokens,192))
+ *   wgrad: slabs of G[n][k] = sum_(b,p) dY[b*tokens + 1 + p][n] pixel(b,p,k) in ws (rovit_wgrad_workspace_bytes(N,768,splits)),
+ *          finished by rovit_wgrad_reduce; dY bf16 (batch*tokens, N). */
+int rovit_patch_embed_fwd(const float* images, const void* W, const float* bias, const float* pos, float* X, int batch, int tokens,
+                          rovit_stream_t stream);
+int rovit_patch_embed_wgrad(const void* dY, int ldy, const float* images, int batch, int tokens, int N, int splits, float* ws,
+                            rovit_stream_t stream);
 int rovit_cls_rows(const float* cls, const float* pos, float* X, int batch, int tokens, rovit_stream_t stream);
 int rovit_cls_norm_fwd(const float* X, const float* gamma, const float* beta, float* feat, float* xhat, float* rstd, int batch,
                        int tokens, float eps, rovit_stream_t stream);

@@ -23,6 +23,7 @@
 // 16-byte fp32 epilogue accesses.  Workgroup ids are remapped so that all column tiles of one row panel (and
 // all output tiles of one M-split in wgrad) run on the same XCD and share that XCD's L2.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -32,7 +33,8 @@ inline bool set_max_lds(const void* fn, size_t bytes) { return rovit_set_max_lds
 constexpr int BK = 64;
 constexpr int LDS_STRIDE = BK + 16;      // bf16 elements; 160-byte rows: conflict-free ds_read_b128 fragments
 
-enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_MUL = 3, EPI_PATCH = 4, EPI_RESID_LN = 5, EPI_LNBWD = 6 };
+enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_MUL = 3, EPI_PATCH = 4, EPI_RESID_LN = 5, EPI_LNBWD = 6,
+       EPI_PATCH_IMG = 7 };   // internal: EPI_PATCH with the A operand gathered from the fp32 NCHW images (rovit_patch_embed_fwd)
 
 struct GemmArgs {
   const bf16* A; int lda;
@@ -46,6 +48,7 @@ struct GemmArgs {
   const float* pos; int tokens;
   int n_tiles;
   float* rstd_out; float eps;   // EPI_RESID_LN: statistics of the LayerNorm fused behind the residual add
+  const float* img;   // EPI_PATCH_IMG: images (B,3,224,224) fp32; row m = (image, patch), column = c*256 + kh*16 + kw
   int dbg;            // developer knob, see rovit_set_gemm_debug (bit 0 skip epilogue stores, 1 skip MFMAs, 2 skip DMA, 3 skip GELU)
 };
 
@@ -108,7 +111,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, f32x4
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] *= (float)q[r];
     *(bf16x4*)(g.out + (size_t)m * g.ldo + n) = pack4(v);
-  } else if (EPI == EPI_PATCH) {
+  } else if (EPI == EPI_PATCH || EPI == EPI_PATCH_IMG) {
     const int np = g.tokens - 1;
     const int b = m / np, p = m - b * np;
     const float4 pe = *(const float4*)(g.pos + (size_t)(p + 1) * g.N + n);
@@ -228,6 +231,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmArgs g)
 // WK == 2 splits K over two waves per column slice; the pair exchanges partial accumulators through LDS and
 // each finishes half of the tile's rows.
 // ------------------------------------------------------------------------------------------------------
+// im2col on the fly (PatchEmbed conv k16 s16 as a GEMM, timm VisionTransformer via /root/reference/models/backbone.py:12-25): the eight
+// consecutive K columns col .. col+7 of patch row m are eight consecutive floats of one image row
+struct F8 { f32x4 lo, hi; };
+__device__ __forceinline__ const float* patch_src(const float* img, int m, int col) {
+  const int b = m / 196, p = m - b * 196;
+  const int ph = p / 14, pw = p - ph * 14;
+  const int c = col >> 8, kh = (col >> 4) & 15, kw = col & 15;
+  return img + (((size_t)b * 3 + c) * 224 + ph * 16 + kh) * 224 + pw * 16 + kw;
+}
+__device__ __forceinline__ F8 load_f8(const float* p) { F8 r; r.lo = *(const f32x4*)p; r.hi = *(const f32x4*)(p + 4); return r; }
+
 template <int KS, int WK, int BM, int EPI>
 __global__ __launch_bounds__(256 * WK, 2) void gemm_ws_kernel(const GemmArgs g, int tiles_per_wg, int n_tiles_m) {
   constexpr int K = KS * 32 * WK;
@@ -271,26 +285,39 @@ __global__ __launch_bounds__(256 * WK, 2) void gemm_ws_kernel(const GemmArgs g, 
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     const int c = tid + i * NT;
-    c_row[i] = c / CPR; c_col[i] = (c - c_row[i] * CPR) * 8;
+    if (EPI == EPI_PATCH_IMG) {
+      // image gather: the tile ROW runs fastest over the lanes, so that a wave reads 32 neighbouring patches x the two
+      // 32-byte halves of one 16-pixel image-row segment = contiguous 2 KB runs (row-major chunk order reads 32 bytes
+      // out of every 896: 94 us instead of 41 + 42 for the im2col pass and its GEMM)
+      c_row[i] = c % BM; c_col[i] = (c / BM) * 8;
+    } else {
+      c_row[i] = c / CPR; c_col[i] = (c - c_row[i] * CPR) * 8;
+    }
   }
   // Two register sets keep the global loads of tiles t+1 and t+2 in flight while tile t is computed: with a
   // single set the next load could only be issued after the previous one had landed (one tile per workgroup in
   // flight = ~25 GB/s per CU, the measured ceiling of the first version of this kernel).
-  bf16x8 rvA[CH], rvB[CH];
-  auto gload = [&](int tile, bf16x8* rv) {
+  constexpr bool IMG = (EPI == EPI_PATCH_IMG);     // A gathered from fp32 images: the raw floats wait in registers, packed at the LDS store
+  using RV = typename std::conditional<IMG, F8, bf16x8>::type;
+  RV rvA[CH], rvB[CH];
+  auto gload = [&](int tile, RV* rv) {
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       if (NCH % NT == 0 || tid + i * NT < NCH) {
         int gr = tile * BM + c_row[i];
         gr = gr < g.M ? gr : g.M - 1;
-        rv[i] = *(const bf16x8*)(g.A + (size_t)gr * g.lda + c_col[i]);
+        if constexpr (IMG) rv[i] = load_f8(patch_src(g.img, gr, c_col[i]));
+        else rv[i] = *(const bf16x8*)(g.A + (size_t)gr * g.lda + c_col[i]);
       }
     }
   };
-  auto lstore = [&](int buf, const bf16x8* rv) {
+  auto lstore = [&](int buf, const RV* rv) {
 #pragma unroll
     for (int i = 0; i < CH; ++i)
-      if (NCH % NT == 0 || tid + i * NT < NCH) *(bf16x8*)(As + (buf * BM + c_row[i]) * STR + c_col[i]) = rv[i];
+      if (NCH % NT == 0 || tid + i * NT < NCH) {
+        if constexpr (IMG) *(bf16x8*)(As + (buf * BM + c_row[i]) * STR + c_col[i]) = pack8(rv[i].lo, rv[i].hi);
+        else *(bf16x8*)(As + (buf * BM + c_row[i]) * STR + c_col[i]) = rv[i];
+      }
   };
 
   gload(tile0, rvA);
@@ -592,6 +619,13 @@ int launch_ws(const GemmArgs& g0, int epi, hipStream_t st) {
   }
   switch (epi) {
     LAUNCHW(EPI_BF16) LAUNCHW(EPI_GELU) LAUNCHW(EPI_RESID) LAUNCHW(EPI_MUL) LAUNCHW(EPI_PATCH) LAUNCHW(EPI_RESID_LN) LAUNCHW(EPI_LNBWD)
+    case EPI_PATCH_IMG:
+      if constexpr (KS * WK * 32 == 768) {
+        if (!set_max_lds((const void*)gemm_ws_kernel<KS, WK, BM, EPI_PATCH_IMG>, lds)) { rovit_set_error("gemm_ws: cannot raise the LDS limit"); return ROVIT_ERR_LAUNCH; }
+        hipLaunchKernelGGL((gemm_ws_kernel<KS, WK, BM, EPI_PATCH_IMG>), grid, block, lds, st, g, tpw, tiles_m);
+        break;
+      }
+      rovit_set_error("gemm_ws: the image-gather epilogue needs K = 768"); return ROVIT_ERR_SHAPE;
     default: rovit_set_error("gemm_ws: unknown epilogue %d", epi); return ROVIT_ERR_SHAPE;
   }
 #undef LAUNCHW
@@ -1231,6 +1265,7 @@ struct WgradArgs {
   int M;
   int splits, rows_per_split, tiles_per_split;
   int patch_tokens;     // >0 (single problem only): dY row of m is m + m/(T-1) + 1 (skip each image's cls row)
+  const float* img;     // PATCH only: when set, the A operand (patch pixels, K = 768) is gathered from these fp32 NCHW images
   int dbg;              // developer knob: bit 0 skip steady-state global loads, bit 1 skip MFMAs
 };
 
@@ -1238,7 +1273,7 @@ struct WgradArgs {
 // wave tile TK/2 x TN/2.  Smaller tiles mean fewer M-splits for the same number of workgroups, i.e. fewer fp32 partial
 // slabs to write and reduce (slab bytes = splits x N x K x 4), at the price of more operand re-reads through the XCD's
 // L2 (every tile of a split streams the same rows; all tiles of a split run on one XCD).
-template <int TN, int TK, bool PATCH>
+template <int TN, int TK, bool PATCH, bool IMG = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   constexpr int SY = wg_stride(TN), SA = wg_stride(TK);
   constexpr int CPRY = TN / 8, CPRA = TK / 8;           // 16-byte chunks per tile row
@@ -1271,9 +1306,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
 
   // Per-thread staging chunks.  Keep the hot loop free of address arithmetic: one clamped row index and one
   // 64-bit multiply-add per chunk and step; the LDS offsets are loop constants.
-  int y_row[CHY], y_lds[CHY], a_row[CHA], a_lds[CHA];
+  int y_row[CHY], y_lds[CHY], a_row[CHA], a_lds[CHA], a_col[CHA];
   const bf16* ybase[CHY];
   const bf16* abase[CHA];
+  using RA = typename std::conditional<IMG, F8, bf16x8>::type;      // IMG: raw pixels wait in registers, packed at the LDS store
 #pragma unroll
   for (int i = 0; i < CHY; ++i) {
     const int c = tid + i * 256;
@@ -1285,13 +1321,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
 #pragma unroll
   for (int i = 0; i < CHA; ++i) {
     const int c = tid + i * 256;
-    a_row[i] = c / CPRA;
-    const int col = (c - a_row[i] * CPRA) * 8;
+    int col;
+    if (IMG) {      // 32 neighbouring patches x both halves of a 16-pixel segment per wave (see gemm_ws_kernel)
+      const int rest = c >> 6, row_hi = rest / (CPRA / 2), pair = rest - row_hi * (CPRA / 2);
+      a_row[i] = (c & 31) + 32 * row_hi;
+      col = (pair * 2 + ((c >> 5) & 1)) * 8;
+    } else {
+      a_row[i] = c / CPRA;
+      col = (c - a_row[i] * CPRA) * 8;
+    }
     a_lds[i] = a_row[i] * SA + col;
+    a_col[i] = k0 + col;
     abase[i] = pr.A + k0 + col;
   }
   const int m_last = g.M - 1;
-  auto load = [&](int mbase, bf16x8* ry, bf16x8* ra) {
+  auto load = [&](int mbase, bf16x8* ry, RA* ra) {
 #pragma unroll
     for (int i = 0; i < CHY; ++i) {
       int m = mbase + y_row[i];
@@ -1303,22 +1347,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
     for (int i = 0; i < CHA; ++i) {
       int m = mbase + a_row[i];
       m = m < m_last ? m : m_last;
-      ra[i] = *(const bf16x8*)(abase[i] + (size_t)m * pr.lda);
+      if constexpr (IMG) ra[i] = load_f8(patch_src(g.img, m, a_col[i]));
+      else ra[i] = *(const bf16x8*)(abase[i] + (size_t)m * pr.lda);
     }
   };
-  auto store = [&](int buf, int mbase, const bf16x8* ry, const bf16x8* ra) {
+  auto tobf = [&](const RA& v) -> bf16x8 {
+    if constexpr (IMG) return pack8(v.lo, v.hi);
+    else return v;
+  };
+  auto store = [&](int buf, int mbase, const bf16x8* ry, const RA* ra) {
     bf16* yd = Ys + buf * WG_MSTEP * SY;
     bf16* ad = As + buf * WG_MSTEP * SA;
     if (mbase + WG_MSTEP <= m_end) {                    // wave-uniform: full step
 #pragma unroll
       for (int i = 0; i < CHY; ++i) *(bf16x8*)(yd + y_lds[i]) = ry[i];
 #pragma unroll
-      for (int i = 0; i < CHA; ++i) *(bf16x8*)(ad + a_lds[i]) = ra[i];
+      for (int i = 0; i < CHA; ++i) *(bf16x8*)(ad + a_lds[i]) = tobf(ra[i]);
     } else {                                            // last, partial step of a split: zero the rows past m_end
 #pragma unroll
       for (int i = 0; i < CHY; ++i) *(bf16x8*)(yd + y_lds[i]) = keep_if(ry[i], mbase + y_row[i] < m_end);
 #pragma unroll
-      for (int i = 0; i < CHA; ++i) *(bf16x8*)(ad + a_lds[i]) = keep_if(ra[i], mbase + a_row[i] < m_end);
+      for (int i = 0; i < CHA; ++i) *(bf16x8*)(ad + a_lds[i]) = keep_if(tobf(ra[i]), mbase + a_row[i] < m_end);
     }
   };
 
@@ -1370,7 +1419,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   };
   // Two register sets keep the global loads of steps s+1 and s+2 in flight while step s runs its MFMAs; the
   // barrier waits for LDS only, so those loads are not drained at it.
-  bf16x8 ryA[CHY], raA[CHA], ryB[CHY], raB[CHA];
+  bf16x8 ryA[CHY], ryB[CHY];
+  RA raA[CHA], raB[CHA];
   load(m_begin, ryA, raA);
   store(0, m_begin, ryA, raA);
   load(m_begin + WG_MSTEP, ryA, raA);
@@ -1533,6 +1583,21 @@ extern "C" int rovit_gemm_nt(const void* A, int lda, const void* W, int ldw, int
   return launch_nt<128, 96, 2, 2>(g, epi, (hipStream_t)stream);
 }
 
+// PatchEmbed forward without the im2col buffer: X[b*tokens + 1 + p][:] = patches(images)[b, p, :] W^T + bias + pos[1 + p]
+// (conv k16 s16 of timm's PatchEmbed as a GEMM whose A tiles are gathered from the fp32 NCHW images and rounded to bf16 on
+// the way into LDS, exactly what rovit_im2col + rovit_gemm_nt(EPI_PATCH) compute).
+extern "C" int rovit_patch_embed_fwd(const float* images, const void* W, const float* bias, const float* pos, float* X, int batch, int tokens,
+                                     rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(images && W && pos && X, ROVIT_ERR_NULL, "patch_embed_fwd: null pointer");
+  ROVIT_CHECK_ARG(batch > 0 && tokens == 197, ROVIT_ERR_SHAPE, "patch_embed_fwd: 224x224 images in 16x16 patches (197 tokens) only");
+  ROVIT_CHECK_ARG(rovit_aligned16(images) && rovit_aligned16(W) && rovit_aligned16(X) && rovit_aligned16(pos), ROVIT_ERR_ALIGN,
+                  "patch_embed_fwd: buffers must be 16-byte aligned");
+  GemmArgs g{};
+  g.A = nullptr; g.lda = 768; g.W = (const bf16*)W; g.ldw = 768; g.M = batch * 196; g.N = 192; g.K = 768; g.bias = bias;
+  g.xres = X; g.ldx = 192; g.pos = pos; g.tokens = tokens; g.img = images; g.dbg = g_gemm_dbg;
+  return launch_ws<12, 2, 32>(g, EPI_PATCH_IMG, (hipStream_t)stream);
+}
+
 // dpre = (dY W2T^T) * gelu'(bf16(H W1^T + b1)): first half of the MLP backward with gelu' recomputed from xhat2
 // (reference arithmetic: autograd of timm Mlp, fc2 then GELU then fc1)
 extern "C" int rovit_gemm_mlp_bwd(const void* dY, int ldy, const void* H, int ldh, const void* W2T, const void* W1, const float* b1,
@@ -1591,7 +1656,8 @@ static void launch_wgrad(const WgradArgs& g0, hipStream_t st) {
   }
   g.tiles_per_split = t;
   const int nwg = g.splits * t;
-  if (g.patch_tokens > 0) hipLaunchKernelGGL((wgrad_kernel<TN, TK, true>), dim3(nwg), dim3(256), 0, st, g);
+  if (g.patch_tokens > 0 && g.img) hipLaunchKernelGGL((wgrad_kernel<TN, TK, true, true>), dim3(nwg), dim3(256), 0, st, g);
+  else if (g.patch_tokens > 0) hipLaunchKernelGGL((wgrad_kernel<TN, TK, true>), dim3(nwg), dim3(256), 0, st, g);
   else hipLaunchKernelGGL((wgrad_kernel<TN, TK, false>), dim3(nwg), dim3(256), 0, st, g);
 }
 
@@ -1623,6 +1689,32 @@ extern "C" int rovit_wgrad(const void* dY, int ldy, const void* A, int lda, int 
     default: rovit_set_error("wgrad: no kernel for tile %d x %d", tn, tk); return ROVIT_ERR_SHAPE;
   }
   ROVIT_CHECK_LAUNCH("wgrad_kernel");
+  return ROVIT_OK;
+}
+
+// Weight gradient of the PatchEmbed projection without an im2col buffer: G[n][k] = sum over (image, patch) rows m of
+// dY[token row of m][n] * pixel(m, k), pixels gathered from the fp32 NCHW images and rounded to bf16 on the way into LDS
+// (what rovit_wgrad(..., patch_tokens) computes from the rovit_im2col buffer).  dY: bf16 (batch*tokens, N) token rows.
+extern "C" int rovit_patch_embed_wgrad(const void* dY, int ldy, const float* images, int batch, int tokens, int N, int splits, float* ws,
+                                       rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(dY && images && ws, ROVIT_ERR_NULL, "patch_embed_wgrad: null pointer");
+  ROVIT_CHECK_ARG(batch > 0 && tokens == 197 && N % 96 == 0 && splits > 0, ROVIT_ERR_SHAPE, "patch_embed_wgrad: unsupported shape");
+  ROVIT_CHECK_ARG(ldy % 8 == 0 && rovit_aligned16(dY) && rovit_aligned16(images), ROVIT_ERR_ALIGN, "patch_embed_wgrad: alignment");
+  const int M = batch * (tokens - 1), K = 768;
+  WgradArgs g{};
+  g.nprob = 1;
+  g.p[0] = WgradProb{(const bf16*)dY, ldy, nullptr, K, N, K, ws, ws + (size_t)splits * N * K, 0, 0};
+  g.M = M;
+  g.splits = splits;
+  g.rows_per_split = ((M + splits - 1) / splits + WG_MSTEP - 1) / WG_MSTEP * WG_MSTEP;
+  g.patch_tokens = tokens;
+  g.img = images;
+  g.dbg = g_gemm_dbg >> 4;
+  // 192-wide output tiles when N allows: the fp32 pixels (twice the bytes of a bf16 im2col row) are then read by one
+  // workgroup per M-split instead of two (61.6 -> 56.3 us at batch 256)
+  if (N % 192 == 0) launch_wgrad<192, 96>(g, (hipStream_t)stream);
+  else launch_wgrad<96, 96>(g, (hipStream_t)stream);
+  ROVIT_CHECK_LAUNCH("wgrad_kernel (patch, image gather)");
   return ROVIT_OK;
 }
 

@@ -321,6 +321,7 @@ class VitFn(torch.autograd.Function):
         ctx.engine, ctx.batch, ctx.need_bwd = engine, B, need_bwd
         if need_bwd:
             ctx.ws = ws
+            ctx.save_for_backward(images)           # the patch-embedding weight gradient gathers its pixels from the batch itself
             ctx.params = params
             ctx.prep_key = engine._prep_key       # (data_ptr, version) of every parameter the bf16 weights were built from
             ctx.grad_taps = dict(engine.grad_taps)
@@ -342,6 +343,7 @@ class VitFn(torch.autograd.Function):
             raise native.RovitHipError('backbone parameters changed between forward and backward (optimizer step or '
                                        'in-place update): the prepared bf16 weights no longer match the saved activations')
         dfeat = _f32c(dfeat)
+        images, = ctx.saved_tensors
         engine.ensure_grads(params)
         fresh = all(p.grad is None for p in params)
         owned = (not fresh) and all(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
@@ -369,11 +371,11 @@ class VitFn(torch.autograd.Function):
         for first, last in ranges:
             if hooked and engine.notify_stream is not None and last > 0:
                 # the range's gradients become visible on the reduction stream; this stream is not stalled
-                call('rovit_vit_backward_notify', ptr(dfeat), parr, ptr(engine.prep), ptr(ctx.ws), garr, ctx.batch, depth,
+                call('rovit_vit_backward_notify', ptr(images), ptr(dfeat), parr, ptr(engine.prep), ptr(ctx.ws), garr, ctx.batch, depth,
                      first, last, stream_ptr(), engine.notify_stream.cuda_stream)
                 engine.range_hook(engine, first, last, True)
             else:
-                call('rovit_vit_backward', ptr(dfeat), parr, ptr(engine.prep), ptr(ctx.ws), garr, ctx.batch, depth,
+                call('rovit_vit_backward', ptr(images), ptr(dfeat), parr, ptr(engine.prep), ptr(ctx.ws), garr, ctx.batch, depth,
                      first, last, stream_ptr())
                 if hooked:
                     engine.range_hook(engine, first, last, False)

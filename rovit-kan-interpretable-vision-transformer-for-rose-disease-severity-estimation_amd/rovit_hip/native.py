@@ -44,8 +44,8 @@ SIGNATURES = {
     'rovit_vit_forward': (_i, [_vp] * 5 + [_i] * 3 + [_vp]),
     'rovit_vit_forward_taps': (_i, [_vp] * 7 + [_i, _i, _vp]),
     'rovit_attention_probs': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
-    'rovit_vit_backward': (_i, [_vp] * 5 + [_i] * 4 + [_vp]),
-    'rovit_vit_backward_notify': (_i, [_vp] * 5 + [_i] * 4 + [_vp] + [_vp]),
+    'rovit_vit_backward': (_i, [_vp] * 6 + [_i] * 4 + [_vp]),
+    'rovit_vit_backward_notify': (_i, [_vp] * 6 + [_i] * 4 + [_vp] + [_vp]),
     'rovit_gemm_nt': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     'rovit_gemm_mlp_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     'rovit_gemm_resid_ln': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp]),
@@ -63,6 +63,8 @@ SIGNATURES = {
     'rovit_layernorm_fwd': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     'rovit_layernorm_bwd': (_i, [_vp] * 5 + [_i, _i, _vp]),
     'rovit_im2col': (_i, [_vp, _vp, _i, _vp]),
+    'rovit_patch_embed_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'rovit_patch_embed_wgrad': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     'rovit_cls_rows': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'rovit_cls_norm_fwd': (_i, [_vp] * 6 + [_i, _i, _f, _vp]),
     'rovit_cls_norm_bwd': (_i, [_vp] * 8 + [_i, _i, _vp]),

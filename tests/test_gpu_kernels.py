@@ -321,6 +321,43 @@ def test_im2col_matches_conv():
     assert torch.equal(col, bf(ref))
 
 
+@pytest.mark.parametrize('B', [1, 3, 37])
+def test_patch_embed_without_im2col_buffer_is_bit_identical_to_the_im2col_path(B):
+    """rovit_patch_embed_fwd / rovit_patch_embed_wgrad gather the conv patches from the fp32 images inside the GEMM and the
+    weight-gradient kernel; they must give the bits of rovit_im2col + rovit_gemm_nt(EPI_PATCH) / rovit_wgrad(patch rows), and
+    the values of the conv itself (PatchEmbed of timm's VisionTransformer, reference models/backbone.py:12-25)."""
+    native = _native()
+    lib = native.load()
+    g = torch.Generator(device=dev()).manual_seed(B)
+    Tk = 197
+    x = torch.randn(B, 3, 224, 224, device=dev(), generator=g)
+    W = bf(torch.randn(192, 768, device=dev(), generator=g) * 0.05)
+    bias = torch.randn(192, device=dev(), generator=g)
+    pos = torch.randn(Tk, 192, device=dev(), generator=g)
+    col = torch.empty(B * 196, 768, device=dev(), dtype=torch.bfloat16)
+    native.call('rovit_im2col', native.ptr(x), native.ptr(col), B, native.stream_ptr())
+    X0 = torch.full((B * Tk, 192), 7.0, device=dev())
+    X1 = X0.clone()
+    native.call('rovit_gemm_nt', native.ptr(col), 768, native.ptr(W), 768, B * 196, 192, 768, native.ptr(bias), 4, None, 0, None,
+                native.ptr(X0), 192, None, 0, native.ptr(pos), Tk, native.stream_ptr())
+    native.call('rovit_patch_embed_fwd', native.ptr(x), native.ptr(W), native.ptr(bias), native.ptr(pos), native.ptr(X1), B, Tk,
+                native.stream_ptr())
+    assert torch.equal(X0, X1)
+    conv = torch.nn.functional.conv2d(bf(x).float(), W.float().view(192, 3, 16, 16), bias, stride=16).flatten(2).transpose(1, 2)
+    got = X1.view(B, Tk, 192)[:, 1:] - pos[1:]
+    assert float((got - conv).abs().max()) < 2e-3 * float(conv.abs().max())
+    assert torch.equal(X1.view(B, Tk, 192)[:, 0], torch.full((B, 192), 7.0, device=dev()))       # cls rows untouched
+    # weight gradient
+    dX = bf(torch.randn(B * Tk, 192, device=dev(), generator=g))
+    M = B * 196
+    splits = lib.rovit_wgrad_splits(M, 192, 768)
+    nws = lib.rovit_wgrad_workspace_bytes(192, 768, splits) // 4
+    ws0, ws1 = torch.empty(nws, device=dev()), torch.empty(nws, device=dev())
+    native.call('rovit_wgrad', native.ptr(dX), 192, native.ptr(col), 768, M, 192, 768, splits, Tk, native.ptr(ws0), native.stream_ptr())
+    native.call('rovit_patch_embed_wgrad', native.ptr(dX), 192, native.ptr(x), B, Tk, 192, splits, native.ptr(ws1), native.stream_ptr())
+    assert torch.equal(ws0, ws1)
+
+
 # ------------------------------------------------------------------ attention -------------------------------
 def _attn_ref(qkv, B, Tk, H):
     q, k, v = qkv.float().view(B, Tk, 3, H, 64).permute(2, 0, 3, 1, 4)

@@ -58,7 +58,10 @@ __device__ __forceinline__ bf16x8 col_frag(const bf16* tile, int r0, int dt, int
 
 // launch bound: 4 waves/SIMD (<= 128 VGPRs) so that TWO 7-wave workgroups share a CU (70 KB of LDS each) and one
 // stages its K/V tiles while the other computes.
-__global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(const AttnArgs a) {
+#ifndef ROVIT_LB_ATTN_FWD
+#define ROVIT_LB_ATTN_FWD 2      // LDS (73 KB) admits two workgroups per CU; asking for four capped the kernel at 64 VGPRs with spills (step 5.99 -> 5.94 ms)
+#endif
+__global__ __launch_bounds__(NW * 64, ROVIT_LB_ATTN_FWD) void attn_fwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) bf16 lds[];
   bf16* Ks = lds;
   bf16* Vs = lds + TP * AST;

@@ -109,27 +109,15 @@ def wgrad_roofline(dev, iters=30):
     ms = _event_avg_ms(dev, run, iters)
     ms_train = _event_avg_ms(dev, run, iters, per_launch=False)
     flops = sum(2.0 * M * n * k for n, k in shapes)
-    # algorithmic bytes per launch: read dY (M*N) and A (M*K) in bf16, write the fp32 partial results
-    # G (N*K per M-split: the kernel's output is the slab set, reduced by the next launch), per problem
+    # algorithmic bytes per launch: read dY (M*N) and A (M*K) in bf16 once, write one fp32 G (N*K), per
+    # problem (the 16 partial slabs the kernel really writes count as traffic, not as algorithmic bytes)
     alg_bytes = sum(2.0 * M * (n + k) + 4.0 * n * k for n, k in shapes)
     gbs = alg_bytes / (ms * 1e-3) / 1e9
-    # the same kernel with 21 M-splits (504 workgroups = both workgroup slots of 252 CUs): faster alone, but the training step
-    # is bound by total bytes and 21 splits write 9 MB more partial slabs per block (6.09 vs 6.05 ms per step), so the
-    # step runs 16; reported for the record
-    s21 = 21
-    ws21 = [torch.empty(lib.rovit_wgrad_workspace_bytes(n, k, s21), dtype=torch.uint8, device=dev) for n, k in shapes]
-    a_ws21 = native.ptr_array(ws21)
-
-    def run21():
-        native.call('rovit_wgrad_multi', a_dy, ldy, a_a, lda, Ns, Ks, a_ws21, 4, M, s21, native.stream_ptr())
-    ms21 = _event_avg_ms(dev, run21, iters)
     return {'bound': 'hbm', 'kernel': f'wgrad_kernel<96,192,false>: weight gradients of one block (qkv+fc2+fc1+proj) in one launch, M=50432, {splits} M-splits',
             'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
             'avg_us': round(ms * 1e3, 2), 'avg_us_back_to_back': round(ms_train * 1e3, 2), 'algorithmic_bytes': alg_bytes,
             'traffic': _pmc_traffic('wgrad_kernel<96,192,false>'),
-            'mfma_tflops': round(flops / (ms * 1e-3) / 1e12, 1),
-            'alone_with_21_splits': {'avg_us': round(ms21 * 1e3, 2), 'frac': round(alg_bytes / (ms21 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                     'note': 'not the step configuration: +9 MB of partial slabs per block costs the step more than the kernel gains'}}
+            'mfma_tflops': round(flops / (ms * 1e-3) / 1e12, 1)}
 
 
 def gemm_roofline(dev, iters=30):

@@ -19,7 +19,7 @@ def means(d, counter):
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 fe, wr = means('fetch', 'FETCH_SIZE'), means('write', 'WRITE_SIZE')
 out = {}
-for name, key in (('wgrad_kernel<96, 192, false>', 'wgrad_kernel<96,192,false>'), ('gemm_ws_dma_kernel<1>', 'gemm_ws_dma_kernel<1>'),
+for name, key in (('wgrad_kernel<96, 192, false, false>', 'wgrad_kernel<96,192,false>'), ('gemm_ws_dma_kernel<1>', 'gemm_ws_dma_kernel<1>'),
                   ('kan_stack_fwd_kernel<32>', 'kan_stack_fwd_kernel<32>'), ('kan_fwd_kernel', 'kan_fwd_kernel'),
                   ('kan_stack_mfma_kernel<4, 4>', 'kan_stack_mfma_kernel<4>'), ('kan_stack_mfma_kernel<18, 1>', 'kan_stack_mfma_kernel<18>')):
     fk = [k for k in fe if name in k]; wk = [k for k in wr if name in k]

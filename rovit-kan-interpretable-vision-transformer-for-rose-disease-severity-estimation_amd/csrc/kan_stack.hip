@@ -317,10 +317,11 @@ struct KanMfmaArgs {
 
 // H = half the padded slot count; FPL = features per lane and sub-chunk (a super-chunk is 8 features: lane (sample, h)
 // owns features 4h .. 4h+3 of it and builds FPL of their rows per sub-chunk); NT = 32-output tiles of the layer.
-template <int H, int FPL, int NT, int L>
+template <int H, int FPL, int NS, int NT, int L>
 __device__ __forceinline__ void km_layer(const KanMfmaArgs& a, float* s_knots, float* s_act, float* s_row, int lane, int b0) {
   constexpr int l = L;
   constexpr int S = 2 * H;
+  constexpr int TS = KM_TS * NS;                             // samples of this wave: lane (smp, hk) serves samples smp + 32 s
   const int in_f = a.dims[l], out_f = a.dims[l + 1];
   const int nk = a.nk[l], nb = nk - 4;
   const int smp = lane & 31, hk = lane >> 5;
@@ -332,20 +333,32 @@ __device__ __forceinline__ void km_layer(const KanMfmaArgs& a, float* s_knots, f
   float* dummy = s_knots + KS_MAX_KNOTS + lane;              // sink of the scattered writes of absent basis terms
   // activation buffers: outputs of even layers in buffer 0 (stride as0), of odd layers in buffer 1 (stride as1)
   const int as_in = (l & 1) ? a.as0 : a.as1, as_out = (l & 1) ? a.as1 : a.as0;
-  const float* src = l == 0 ? nullptr : s_act + ((l & 1) ? 0 : KM_TS * a.as0) + smp * as_in;
-  const int bs = b0 + smp < a.B ? b0 + smp : a.B - 1;
-  const float* xrow = a.x + (size_t)bs * in_f;
+  const float* src = l == 0 ? nullptr : s_act + ((l & 1) ? 0 : TS * a.as0) + smp * as_in;
+  const float* xrow[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int bs = b0 + smp + 32 * s < a.B ? b0 + smp + 32 * s : a.B - 1;
+    xrow[s] = l == 0 ? a.x + (size_t)bs * in_f : src + 32 * s * as_in;
+  }
   const float* wl = a.Wm[l] + lane;
-  f32x16 acc[NT];
+  f32x16 acc[NS][NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int s = 0; s < NS; ++s)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][t][r] = 0.f;
 
-  f32x4 xn = l == 0 ? *(const f32x4*)(xrow + 4 * hk) : *(const f32x4*)(src + 4 * hk);
+  f32x4 xn[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) xn[s] = *(const f32x4*)(xrow[s] + 4 * hk);
   for (int i0 = 0; i0 < in_f; i0 += 8) {
-    const f32x4 xv4 = xn;
-    if (i0 + 8 < in_f) xn = l == 0 ? *(const f32x4*)(xrow + i0 + 8 + 4 * hk) : *(const f32x4*)(src + i0 + 8 + 4 * hk);
+    f32x4 xv4[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      xv4[s] = xn[s];
+      if (i0 + 8 < in_f) xn[s] = *(const f32x4*)(xrow[s] + i0 + 8 + 4 * hk);
+    }
 #pragma unroll
     for (int sc = 0; sc < 4 / FPL; ++sc) {
       // ---- the sub-chunk's weights: issued first, they land while the rows are built
@@ -359,89 +372,101 @@ __device__ __forceinline__ void km_layer(const KanMfmaArgs& a, float* s_knots, f
       }
       // ---- build the dense slot rows of this sub-chunk: local feature f = 2 * u + hk  <->  input i0 + 4 * hk + sc * FPL + u
 #pragma unroll
-      for (int u = 0; u < FPL; ++u) {
-        const float xv = xv4[sc * FPL + u];
-        const B4 bq = km_basis(tanhf(xv), s_knots, t0, tl, kcut, inv_h, nb);
-        float* row = s_row + ((2 * u + hk) * KM_TS + smp) * S;
+      for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int z = 0; z < S / 4; ++z) *(f32x4*)(row + 4 * z) = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // slot s lives at position (s & 1) * H + (s >> 1): the two slot parities are the two K rows of an MFMA step
+        for (int u = 0; u < FPL; ++u) {
+          const float xv = xv4[s][sc * FPL + u];
+          const B4 bq = km_basis(tanhf(xv), s_knots, t0, tl, kcut, inv_h, nb);
+          float* row = s_row + ((2 * u + hk) * TS + 32 * s + smp) * S;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int sidx = bq.j - m;                         // < 0: left edge lost the term, or the sample is beyond the cutoff
-          float* dst = sidx >= 0 ? row + ((sidx & 1) * H + (sidx >> 1)) : dummy;
-          *dst = bq.v[m];
+          for (int z = 0; z < S / 4; ++z) *(f32x4*)(row + 4 * z) = (f32x4){0.f, 0.f, 0.f, 0.f};
+          // slot s lives at position (s & 1) * H + (s >> 1): the two slot parities are the two K rows of an MFMA step
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int sidx = bq.j - m;                       // < 0: left edge lost the term, or the sample is beyond the cutoff
+            float* dst = sidx >= 0 ? row + ((sidx & 1) * H + (sidx >> 1)) : dummy;
+            *dst = bq.v[m];
+          }
+          row[(nb & 1) * H + (nb >> 1)] = xv;
         }
-        row[(nb & 1) * H + (nb >> 1)] = xv;
-      }
       __syncthreads();
       // ---- contraction of the 2 * FPL features of the sub-chunk
 #pragma unroll
       for (int f = 0; f < 2 * FPL; ++f) {
-        const float* rp = s_row + (f * KM_TS + smp) * S + hk * H;
-        float bv[H];
-        if (H % 4 == 0) {
+        float bv[NS][H];
 #pragma unroll
-          for (int z = 0; z < H / 4; ++z) { const f32x4 v = *(const f32x4*)(rp + 4 * z); bv[4 * z] = v[0]; bv[4 * z + 1] = v[1]; bv[4 * z + 2] = v[2]; bv[4 * z + 3] = v[3]; }
-        } else {
+        for (int s = 0; s < NS; ++s) {
+          const float* rp = s_row + (f * TS + 32 * s + smp) * S + hk * H;
+          if (H % 4 == 0) {
 #pragma unroll
-          for (int z = 0; z < H / 2; ++z) { const float2 v = *(const float2*)(rp + 2 * z); bv[2 * z] = v.x; bv[2 * z + 1] = v.y; }
+            for (int z = 0; z < H / 4; ++z) { const f32x4 v = *(const f32x4*)(rp + 4 * z); bv[s][4 * z] = v[0]; bv[s][4 * z + 1] = v[1]; bv[s][4 * z + 2] = v[2]; bv[s][4 * z + 3] = v[3]; }
+          } else {
+#pragma unroll
+            for (int z = 0; z < H / 2; ++z) { const float2 v = *(const float2*)(rp + 2 * z); bv[s][2 * z] = v.x; bv[s][2 * z + 1] = v.y; }
+          }
         }
 #pragma unroll
         for (int q = 0; q < H; ++q)
 #pragma unroll
           for (int t = 0; t < NT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[f][q * NT + t], bv[q], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+              acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[f][q * NT + t], bv[s][q], acc[s][t], 0, 0, 0);
       }
       __syncthreads();
     }
   }
   // ---- bias, activation; hand the outputs to the next layer (LDS) and to HBM
-  float* dst = s_act + ((l & 1) ? KM_TS * a.as0 : 0) + smp * as_out;
-  const bool live = b0 + smp < a.B;
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int s = 0; s < NS; ++s) {
+    float* dst = s_act + ((l & 1) ? TS * a.as0 : 0) + (32 * s + smp) * as_out;
+    const int b = b0 + 32 * s + smp;
+    const bool live = b < a.B;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int o = 32 * t + 8 * g + 4 * hk;
-      float z[4];
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v = acc[t][4 * g + e] + (o + e < out_f ? a.lb[l][o + e] : 0.f);
-        v = a.act[l] == ROVIT_ACT_RELU ? fmaxf(v, 0.f) : (a.act[l] == ROVIT_ACT_SIGMOID3 ? 3.f / (1.f + __expf(-v)) : v);
-        z[e] = v;
+      for (int g = 0; g < 4; ++g) {
+        const int o = 32 * t + 8 * g + 4 * hk;
+        float z[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[s][t][4 * g + e] + (o + e < out_f ? a.lb[l][o + e] : 0.f);
+          v = a.act[l] == ROVIT_ACT_RELU ? fmaxf(v, 0.f) : (a.act[l] == ROVIT_ACT_SIGMOID3 ? 3.f / (1.f + __expf(-v)) : v);
+          z[e] = v;
+        }
+        if (o < as_out) *(f32x4*)(dst + o) = (f32x4){z[0], z[1], z[2], z[3]};
+        if (live) {
+          if (o + 3 < out_f) *(f32x4*)(a.out[l] + (size_t)b * out_f + o) = (f32x4){z[0], z[1], z[2], z[3]};
+          else
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (o + e < out_f) a.out[l][(size_t)b * out_f + o + e] = z[e];
+        }
       }
-      if (o < as_out) *(f32x4*)(dst + o) = (f32x4){z[0], z[1], z[2], z[3]};
-      if (live) {
-        if (o + 3 < out_f) *(f32x4*)(a.out[l] + (size_t)(b0 + smp) * out_f + o) = (f32x4){z[0], z[1], z[2], z[3]};
-        else
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (o + e < out_f) a.out[l][(size_t)(b0 + smp) * out_f + o + e] = z[e];
-      }
-    }
+  }
 }
 
-template <int H, int FPL, int L>
+template <int H, int FPL, int NS, int L>
 __device__ __forceinline__ void km_layer_nt(const KanMfmaArgs& a, float* s_knots, float* s_act, float* s_row, int lane, int b0) {
-  if (a.dims[L + 1] > 32) km_layer<H, FPL, 2, L>(a, s_knots, s_act, s_row, lane, b0);
-  else km_layer<H, FPL, 1, L>(a, s_knots, s_act, s_row, lane, b0);
+  if (a.dims[L + 1] > 32) km_layer<H, FPL, NS, 2, L>(a, s_knots, s_act, s_row, lane, b0);
+  else km_layer<H, FPL, NS, 1, L>(a, s_knots, s_act, s_row, lane, b0);
 }
 
-template <int H, int FPL>
+// NS = 32-sample tiles per wave.  NS = 1: 18.7 KB (G = 5) / 19.7 KB (G = 32) of LDS for the default stack, eight workgroups per
+// CU, all 2048 waves of a 65536-sample batch resident together.  NS = 2: every weight fragment fetched from L2 feeds two
+// MFMAs (the kernel is bound by streaming the weights through L2 once per wave), 36 / 39 KB, four workgroups per CU.
+template <int H, int FPL, int NS>
 __global__ __launch_bounds__(64) void kan_stack_mfma_kernel(const KanMfmaArgs a) {
-  // 18.7 KB (G = 5) / 19.7 KB (G = 32) for the default stack: eight workgroups per CU, so that the 2048 waves of a
-  // 65536-sample batch are resident together (one more KB and a quarter of them would wait for a second round)
   extern __shared__ __attribute__((aligned(16))) float km_smem[];
   float* s_knots = km_smem;                                  // [64] knots + [64] write sink
-  float* s_row = s_knots + 2 * KS_MAX_KNOTS;                 // [2 FPL][32][2H]
-  float* s_act = s_row + 2 * FPL * KM_TS * 2 * H;            // [32][as0] + [32][as1]
+  float* s_row = s_knots + 2 * KS_MAX_KNOTS;                 // [2 FPL][32 NS][2H]
+  float* s_act = s_row + 2 * FPL * KM_TS * NS * 2 * H;       // [32 NS][as0] + [32 NS][as1]
   const int lane = threadIdx.x;
-  const int b0 = blockIdx.x * KM_TS;
-  km_layer_nt<H, FPL, 0>(a, s_knots, s_act, s_row, lane, b0);
-  if (a.nl > 1) km_layer_nt<H, FPL, 1>(a, s_knots, s_act, s_row, lane, b0);
-  if (a.nl > 2) km_layer_nt<H, FPL, 2>(a, s_knots, s_act, s_row, lane, b0);
-  if (a.nl > 3) km_layer_nt<H, FPL, 3>(a, s_knots, s_act, s_row, lane, b0);
+  const int b0 = blockIdx.x * KM_TS * NS;
+  km_layer_nt<H, FPL, NS, 0>(a, s_knots, s_act, s_row, lane, b0);
+  if (a.nl > 1) km_layer_nt<H, FPL, NS, 1>(a, s_knots, s_act, s_row, lane, b0);
+  if (a.nl > 2) km_layer_nt<H, FPL, NS, 2>(a, s_knots, s_act, s_row, lane, b0);
+  if (a.nl > 3) km_layer_nt<H, FPL, NS, 3>(a, s_knots, s_act, s_row, lane, b0);
 }
 
 // half the padded slot count of a layer with nb basis functions (+1 slot for the Linear term), rounded up to even
@@ -574,11 +599,17 @@ extern "C" int rovit_kan_stack_fwd_mfma(const float* x, const float* const* wm, 
     if (l & 1) a.as1 = w > a.as1 ? w : a.as1; else a.as0 = w > a.as0 ? w : a.as0;
   }
   if (a.as1 == 0) a.as1 = 4;
-  const int grid = (batch + KM_TS - 1) / KM_TS;
   const int fpl = H == 4 ? 4 : 1;
-  const size_t lds = (2 * KS_MAX_KNOTS + (size_t)2 * fpl * KM_TS * 2 * H + (size_t)KM_TS * (a.as0 + a.as1)) * sizeof(float);
-  if (H == 4) hipLaunchKernelGGL((kan_stack_mfma_kernel<4, 4>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((kan_stack_mfma_kernel<18, 1>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
+  // two sample tiles per wave halve the weight traffic through L2 but leave one wave per SIMD: pays when the MFMA phase
+  // dominates and the batch still gives every SIMD a wave (G = 32 at batch 65536: 696 -> 618 us; G = 5: 186 -> 210 us, not used)
+  static const int ns_env = getenv("ROVIT_KAN_MFMA_NS") ? atoi(getenv("ROVIT_KAN_MFMA_NS")) : 0;
+  const int ns = ns_env ? ns_env : ((H == 18 && batch >= 49152) ? 2 : 1);
+  const int grid = (batch + KM_TS * ns - 1) / (KM_TS * ns);
+  const size_t lds = (2 * KS_MAX_KNOTS + (size_t)2 * fpl * KM_TS * ns * 2 * H + (size_t)KM_TS * ns * (a.as0 + a.as1)) * sizeof(float);
+  if (H == 4 && ns == 1) hipLaunchKernelGGL((kan_stack_mfma_kernel<4, 4, 1>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
+  else if (H == 4) hipLaunchKernelGGL((kan_stack_mfma_kernel<4, 4, 2>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
+  else if (ns == 1) hipLaunchKernelGGL((kan_stack_mfma_kernel<18, 1, 1>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((kan_stack_mfma_kernel<18, 1, 2>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
   ROVIT_CHECK_LAUNCH("kan_stack_mfma_kernel");
   return ROVIT_OK;
 }

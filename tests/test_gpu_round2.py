@@ -669,3 +669,30 @@ def test_ragged_batches_full_model_forward_and_backward_vs_oracle(B):
             assert rel < 1e-3, (k, rel)
         worst = max(worst, rel)
     print(f'B={B} depth={depth}: worst relative gradient error {worst:.3e}')
+
+
+@pytest.mark.parametrize('num_knots', [5, 32])
+def test_matrix_core_kan_stack_at_batch_65536_matches_the_valu_stack(num_knots):
+    """The streaming configuration of the bench (one wave per 32 samples at G=5, two sample tiles per wave at G=32): every
+    layer output of rovit_kan_stack_fwd_mfma against rovit_kan_stack_fwd (itself checked against the oracle above) on the same
+    65536 samples, and a 4096-sample slice against the CPU oracle."""
+    from models.kan import KANSeverityModule
+    layers, B = [192, 64, 16, 1], 65536
+    g = torch.Generator().manual_seed(num_knots)
+    sd = ref_cpu.init_kan_state(layers, num_knots, 3, g)
+    m = KANSeverityModule(layers, num_knots, 3)
+    m.load_state_dict(sd)
+    m = m.to(dev())
+    x = (torch.randn(B, 192, generator=g) * 1.5).to(dev())
+    assert all(p[2] is not None for p in m._prepared())
+    m.fused_min_batch, m.mfma_min_batch = 1, 1 << 30
+    with torch.no_grad():
+        valu = m.get_activation_trajectory(x)
+        m.mfma_min_batch = 1
+        mfma = m.get_activation_trajectory(x)
+    for i in range(1, 4):
+        d = float((valu[i] - mfma[i]).abs().max())
+        print(f'G={num_knots} layer {i}: max |mfma - valu| = {d:.2e}')
+        assert d < 1e-4, (i, d)
+    ref = ref_cpu.kan_module_forward(x[:4096].cpu(), sd)
+    assert float((mfma[-1][:4096].cpu() - ref).abs().max()) < 2e-4

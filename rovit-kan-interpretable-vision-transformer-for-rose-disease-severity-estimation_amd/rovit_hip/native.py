@@ -117,6 +117,11 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
                             'there is no CPU fallback in the product path')
     if not t.is_contiguous():
         raise RovitHipError('non-contiguous tensor passed to a HIP kernel')
+    if t.device.index != torch.cuda.current_device():
+        # kernels are enqueued on the CURRENT device's stream (stream_ptr): one process (or at least one current device)
+        # per GPU, as the data-parallel launcher sets it up; a tensor of another device would be read by the wrong GPU
+        raise RovitHipError(f'tensor on cuda:{t.device.index} but the current device is cuda:{torch.cuda.current_device()}: '
+                            'call torch.cuda.set_device() / use `with torch.cuda.device(...)` around the model call')
     return t.data_ptr()
 
 

@@ -288,7 +288,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=256)
-    ap.add_argument('--buckets', type=int, default=3)
+    ap.add_argument('--buckets', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--roofline-only', action='store_true',
                     help='run only the roofline kernel measurements (the command profiles/r02_roofline_kernel_stats.csv and the PMC passes are taken from)')

@@ -1735,7 +1735,11 @@ int rovit_wgrad_batch(const RovitWgradDesc* descs, int n, int M, int splits, rov
   g.splits = splits;
   g.rows_per_split = ((M + splits - 1) / splits + WG_MSTEP - 1) / WG_MSTEP * WG_MSTEP;
   g.dbg = g_gemm_dbg >> 4;
-  launch_wgrad<96, 192>(g, (hipStream_t)stream);
+  // a lone problem (the qkv weight gradient flushed at the end of a data-parallel block range): 96 x 96 tiles give twice the
+  // workgroups for the same 16 M-splits (96 -> 192); every element still sums the same rows in the same order, so the
+  // result is bit-identical to the merged launch's
+  if (n == 1 && g.p[0].K % 96 == 0) launch_wgrad<96, 96>(g, (hipStream_t)stream);
+  else launch_wgrad<96, 192>(g, (hipStream_t)stream);
   ROVIT_CHECK_LAUNCH("wgrad_kernel (batch)");
   return ROVIT_OK;
 }

@@ -4,7 +4,8 @@ The reference is single-process (no collectives anywhere), 
 independent (LayerNorm only), every rank holds a full replica, and the only exchange is one averaged all-reduce of
 the gradients per step.  The backbone's gradients live in ONE flat fp32 buffer (VitEngine.grad_flat) written by the
 HIP backward block range by block range; each finished range is all-reduced on a side stream while the next range's
-kernels run (bucketed overlap, 3 buckets tapering 6 : 4 : 2 blocks = 10.6 / 7.1 / 4.1 MB: large enough for xGMI's
+kernels run (bucketed overlap; default 2 buckets tapering 8 : 4 blocks = 14.2 / 7.1 MB -- every extra bucket costs 0.09 ms
+of range hand-over on one MI355X, measured with a one-rank RCCL group; 3 buckets taper 6 : 4 : 2 blocks = 10.6 / 7.1 / 4.1 MB: large enough for xGMI's
 per-link bandwidth, and the last bucket, whose all-reduce is exposed, is the smallest).  Head/KAN gradients (0.7 MB) go in one flat bucket after backward.
 
 The class only needs ``flat`` tensors and ranges, so its bucket logic is exercised on CPU with the gloo backend.
@@ -95,7 +96,7 @@ class FlatBucketAllReduce:
 class GradSync:
     """Wires FlatBucketAllReduce into a RoViTKAN model: backbone buckets overlap with backward, heads/KAN after."""
 
-    def __init__(self, model, buckets: int = 3, group=None, force: bool = False, broadcast_init: bool = True):
+    def __init__(self, model, buckets: int = 2, group=None, force: bool = False, broadcast_init: bool = True):
         self.model = model
         self.engine = model.backbone.model.engine
         self.depth = model.backbone.model.depth

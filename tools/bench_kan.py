@@ -71,6 +71,18 @@ def main():
             for (xi, w, k, lw, lb, o, fi, fo, nk, act) in raw:
                 lib.rovit_kan_layer_fwd(xi, w, k, lw, lb, o, B, fi, fo, nk, act, sp)
         t_layers = timeit(per_layer, 50)
+        # backward kernels only (direct C-ABI calls on the forward's activations, gradients preallocated)
+        gouts = [torch.randn_like(o) for o in outs]
+        dxs = [torch.empty_like(t) for t in ins]
+        dws = [(torch.empty_like(l.spline_weights), torch.empty_like(l.linear.weight), torch.empty_like(l.linear.bias)) for l in m.kan_layers]
+        braw = [(ptr(ins[i]), ptr(l.spline_weights), ptr(l.knots), ptr(l.linear.weight), ptr(outs[i]), ptr(gouts[i]), ptr(dxs[i]),
+                 ptr(dws[i][0]), ptr(dws[i][1]), ptr(dws[i][2]), B, l.in_features, l.out_features, l.knots.numel(),
+                 ACT_SIGMOID3 if i == n - 1 else ACT_RELU, 0, sp) for i, l in enumerate(m.kan_layers)]
+
+        def per_layer_bwd():
+            for r in reversed(braw):
+                lib.rovit_kan_layer_bwd(*r)
+        t_bwd = timeit(per_layer_bwd, 20)
         xg = x.clone().requires_grad_(True)
 
         def fb():
@@ -80,7 +92,7 @@ def main():
         t_fb = timeit(fb, 10)
         alg = kan_bytes(layers, nb, B)
         print(json.dumps({'shape': name, 'layers': layers, 'num_knots': G, 'batch': B, 'fused_fwd_us': round(t_fused, 1),
-                          'per_layer_fwd_us': round(t_layers, 1), 'fwd_bwd_us': round(t_fb, 1), 'algorithmic_bytes_fwd': alg,
+                          'per_layer_fwd_us': round(t_layers, 1), 'per_layer_bwd_kernels_us': round(t_bwd, 1), 'fwd_bwd_us': round(t_fb, 1), 'algorithmic_bytes_fwd': alg,
                           'fused_fwd_GBps': round(alg / t_fused / 1e3, 1), 'per_layer_fwd_GBps': round(kan_bytes(layers, nb, B, False) / t_layers / 1e3, 1),
                           'speedup_fwd': round(t_layers / t_fused, 2),
                           'mfma_fwd_us': None if t_mfma is None else round(t_mfma, 1),

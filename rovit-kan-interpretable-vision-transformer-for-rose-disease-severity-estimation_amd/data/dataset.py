@@ -110,13 +110,19 @@ class RoseLeafDataset(Dataset):
 class DeviceBatchLoader:
     """DataLoader stand-in for a device-resident synthetic dataset: ``.dataset`` is a ``Subset`` (so
     ``loader.dataset.dataset`` is the ``RoseLeafDataset``, as scripts/train.py:110 expects), ``len()`` = batches,
-    iteration yields ``(images, class_labels, severity_labels)`` sliced on the device (one index_select per tensor)."""
+    iteration yields ``(images, class_labels, severity_labels)``: the images sliced on the device (one index_select), the
+    two label vectors as HOST tensors like a torch DataLoader's -- the reference's Trainer moves them with ``.to(device)``
+    (training/trainer.py:79-82) and its Evaluator calls ``.numpy()`` on them (evaluation/evaluator.py:58,60).
+    ``labels_on_device=True`` keeps them on the device instead (no host involvement at all in the step)."""
 
-    def __init__(self, subset: Subset, batch_size: int, shuffle: bool, seed: int = 0, drop_last: bool = False):
+    def __init__(self, subset: Subset, batch_size: int, shuffle: bool, seed: int = 0, drop_last: bool = False,
+                 labels_on_device: bool = False):
         self.dataset, self.batch_size, self.shuffle, self.drop_last = subset, batch_size, shuffle, drop_last
+        self.labels_on_device = labels_on_device
         self._gen = torch.Generator().manual_seed(seed)
         base: RoseLeafDataset = subset.dataset
-        self._idx = torch.as_tensor(subset.indices, dtype=torch.long, device=base.images.device)
+        self._idx = torch.as_tensor(subset.indices, dtype=torch.long)
+        self._labels_host, self._sev_host = base.labels.cpu(), base.severities.cpu()
 
     def __len__(self) -> int:
         n = self._idx.numel()
@@ -126,13 +132,18 @@ class DeviceBatchLoader:
         base: RoseLeafDataset = self.dataset.dataset
         order = self._idx
         if self.shuffle:
-            order = order[torch.randperm(order.numel(), generator=self._gen).to(order.device)]
+            order = order[torch.randperm(order.numel(), generator=self._gen)]
+        order_dev = order.to(base.images.device, non_blocking=True)
         for b in range(len(self)):
-            sel = order[b * self.batch_size:(b + 1) * self.batch_size]
+            lo, hi = b * self.batch_size, (b + 1) * self.batch_size
+            sel = order_dev[lo:hi]
             imgs = base.images.index_select(0, sel)
             if base.transform is not None:
                 imgs = base.transform(imgs)
-            yield imgs, base.labels.index_select(0, sel), base.severities.index_select(0, sel)
+            if self.labels_on_device:
+                yield imgs, base.labels.index_select(0, sel), base.severities.index_select(0, sel)
+            else:
+                yield imgs, self._labels_host.index_select(0, order[lo:hi]), self._sev_host.index_select(0, order[lo:hi])
 
 
 def _split(n: int, frac: float, seed: int) -> Tuple[List[int], List[int]]:

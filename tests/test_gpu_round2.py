@@ -245,8 +245,9 @@ def test_trainer_shaped_steps_on_the_synthetic_device_loader():
     model.eval()
     with torch.no_grad():
         for images, cl, sv in val_loader:
+            assert images.is_cuda and not cl.is_cuda and not sv.is_cuda      # labels arrive on the host, like a DataLoader's
             out = model(images)
-            assert torch.isfinite(loss_fn(out, cl, sv, 4)['total_loss'])
+            assert torch.isfinite(loss_fn(out, cl.to(dev()), sv.to(dev()), 4)['total_loss'])
 
 
 def test_autocast_and_gradscaler_call_path_of_the_reference_trainer():
@@ -696,3 +697,75 @@ def test_matrix_core_kan_stack_at_batch_65536_matches_the_valu_stack(num_knots):
         assert d < 1e-4, (i, d)
     ref = ref_cpu.kan_module_forward(x[:4096].cpu(), sd)
     assert float((mfma[-1][:4096].cpu() - ref).abs().max()) < 2e-4
+
+
+def test_evaluator_shaped_loop_reproduces_the_oracle_metrics():
+    """evaluation/evaluator.py:25-110 against the drop-in: the test loader's batches go through ``model(images)`` under
+    no_grad, predictions are collected exactly as Evaluator.evaluate does (softmax / argmax, kan_severity.squeeze(),
+    exp(0.5 log_var), ``class_labels.numpy()`` on the host labels), and the metrics of evaluation/metrics.py:9-61 (accuracy,
+    macro F1, MAE, Spearman rho, Brier score, ECE; restated below) are computed.  In the reference-precision mode every
+    prediction must equal the CPU oracle's (identical classes, severity to 1e-3), hence identical metrics; the fps() protocol
+    (metrics.py:63-93) runs on the same model."""
+    import time
+    from scipy.stats import spearmanr
+    from sklearn.metrics import f1_score
+    from data.dataset import create_dataloaders
+    from data.transforms import original_transforms
+    sd = ref_cpu.init_rovit_state(seed=23)
+    model = _full_model(sd).eval()
+    _, _, test_loader = create_dataloaders('data/Augmented Image', 'data/Original Image', CLASS_NAMES, SEVERITY,
+                                           original_transform=original_transforms(), batch_size=8, synthetic=96, seed=7, device=dev())
+
+    def collect(forward):
+        preds, labels, sev_p, sev_t, probs, unc = [], [], [], [], [], []
+        with torch.no_grad():
+            for images, class_labels, severity_labels in test_loader:
+                outputs = forward(images)
+                p = torch.softmax(outputs['cls_logits'], dim=1)
+                preds.append(torch.argmax(p, dim=1).cpu().numpy())
+                labels.append(class_labels.numpy())
+                sev_p.append(outputs['kan_severity'].squeeze().cpu().numpy())
+                sev_t.append(severity_labels.numpy())
+                probs.append(p.cpu().numpy())
+                unc.append(torch.exp(0.5 * outputs['log_var']).cpu().numpy())
+        return [np.concatenate(v) for v in (preds, labels, sev_p, sev_t, probs, unc)]
+
+    def metrics(y_pred, y_true, s_pred, s_true, y_prob):
+        onehot = np.zeros_like(y_prob)
+        onehot[np.arange(len(y_true)), y_true] = 1
+        conf, acc = y_prob.max(1), (y_prob.argmax(1) == y_true).astype(float)
+        ece = 0.0
+        edges = np.linspace(0, 1, 11)
+        for lo, hi in zip(edges[:-1], edges[1:]):
+            m = (conf > lo) & (conf <= hi)
+            if m.mean() > 0:
+                ece += abs(conf[m].mean() - acc[m].mean()) * m.mean()
+        return {'accuracy': float(np.mean(y_true == y_pred) * 100), 'macro_f1': float(f1_score(y_true, y_pred, average='macro') * 100),
+                'mae': float(np.mean(np.abs(s_true - s_pred))), 'spearman_rho': float(spearmanr(s_true, s_pred)[0]),
+                'brier_score': float(np.mean(np.sum((y_prob - onehot) ** 2, axis=1))), 'ece': float(ece)}
+
+    model.backbone.model.precision = 'fp32'
+    got = collect(lambda im: model(im))
+    ref = collect(lambda im: ref_cpu.rovit_forward(im.cpu(), sd, 4))
+    model.backbone.model.precision = 'bf16'
+    assert len(got[0]) == 24 and np.array_equal(got[1], ref[1])
+    assert np.array_equal(got[0], ref[0])                                  # identical predicted classes
+    assert np.abs(got[2] - ref[2]).max() < 1e-3 and np.abs(got[4] - ref[4]).max() < 1e-4 and np.abs(got[5] - ref[5]).max() < 1e-4
+    mg, mr = metrics(*got[:5]), metrics(*ref[:5])
+    print('metrics (HIP fp32 mode / oracle):', {k: (round(mg[k], 5), round(mr[k], 5)) for k in mg})
+    for k in mg:
+        assert abs(mg[k] - mr[k]) < 1e-3 * max(1.0, abs(mr[k])), (k, mg[k], mr[k])
+    # the default bf16 path through the same loop: finite, bounded, probabilities normalised
+    gb = collect(lambda im: model(im))
+    assert np.isfinite(gb[2]).all() and gb[2].min() >= 0.0 and gb[2].max() <= 3.0 and np.allclose(gb[4].sum(1), 1.0, atol=1e-5)
+    # fps() protocol of metrics.py:63-93 (batch 1, 10 warm-up, n timed forwards)
+    dummy = torch.randn(1, 3, 224, 224).to(dev())
+    with torch.no_grad():
+        for _ in range(10):
+            model(dummy)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(20):
+            model(dummy)
+        torch.cuda.synchronize()
+    assert 20 / (time.time() - t0) > 36.7          # the reference's published backbone-only CPU figure (README.md:340)

@@ -769,3 +769,84 @@ def test_evaluator_shaped_loop_reproduces_the_oracle_metrics():
             model(dummy)
         torch.cuda.synchronize()
     assert 20 / (time.time() - t0) > 36.7          # the reference's published backbone-only CPU figure (README.md:340)
+
+
+class _AblationShaped(torch.nn.Module):
+    """experiments/ablation.py:36-133 restated: the reference composes the drop-in's modules ONE BY ONE (backbone, heads and
+    KAN module called standalone, optional heads removed, freeze by looping over backbone.parameters())."""
+
+    def __init__(self, remove_ordinal=False, remove_uncertainty=False, remove_kan=False):
+        super().__init__()
+        from models.backbone import DeiTTinyBackbone
+        from models.heads import ClassificationHead, OrdinalHead, UncertaintyHead
+        from models.kan import KANSeverityModule
+        self.backbone = DeiTTinyBackbone(pretrained=False, freeze=False)
+        e = self.backbone.embed_dim
+        self.classification_head = ClassificationHead(embed_dim=e, hidden_dim=128, num_classes=4, dropout=0.3)
+        self.ordinal_head = None if remove_ordinal else OrdinalHead(embed_dim=e, hidden_dim=128, num_classes=4, dropout=0.3)
+        self.uncertainty_head = None if remove_uncertainty else UncertaintyHead(embed_dim=e, hidden_dim=128, dropout=0.3)
+        self.kan_module = None if remove_kan else KANSeverityModule(layers=[192, 64, 16, 1], num_knots=5, degree=3)
+        self.curriculum_stage = 0
+
+    def forward(self, x):
+        f = self.backbone(x)
+        out = {'cls_logits': self.classification_head(f), 'features': f,
+               'ordinal_logits': self.ordinal_head(f) if self.ordinal_head is not None else None, 'mu': None, 'log_var': None,
+               'kan_severity': self.kan_module(f) if self.kan_module is not None else None}
+        if self.uncertainty_head is not None:
+            out['mu'], out['log_var'] = self.uncertainty_head(f)
+        return out
+
+    def freeze_backbone(self):
+        for p in self.backbone.parameters():
+            p.requires_grad = False
+
+    def unfreeze_backbone(self):
+        for p in self.backbone.parameters():
+            p.requires_grad = True
+
+
+@pytest.mark.parametrize('variant', ['full', 'no_kan', 'no_ordinal_no_uncertainty'])
+def test_ablation_shaped_composition_of_standalone_modules_trains(variant):
+    """The standalone call path of every module (experiments/ablation.py:92-124), the reference optimizer grouping on a model
+    that is not RoViTKAN (training/optimizer.py:7-32) and JointLoss with absent heads: the full composition equals RoViTKAN
+    on the same weights; every variant trains (frozen first step, then unfrozen) with finite, decreasing loss."""
+    from types import SimpleNamespace
+    from rovit_hip.losses import JointLoss
+    from rovit_hip.optim import build_optimizer
+    kw = {'full': {}, 'no_kan': {'remove_kan': True}, 'no_ordinal_no_uncertainty': {'remove_ordinal': True, 'remove_uncertainty': True}}[variant]
+    sd = ref_cpu.init_rovit_state(seed=31)
+    m = _AblationShaped(**kw)
+    missing = m.load_state_dict(sd, strict=False)
+    assert not missing.missing_keys                    # removed heads only leave unexpected keys behind
+    m = m.to(dev())
+    x = torch.randn(16, 3, 224, 224, generator=torch.Generator().manual_seed(1)).to(dev())
+    y = torch.randint(0, 4, (16,), generator=torch.Generator().manual_seed(2)).to(dev())
+    if variant == 'full':
+        full = _full_model(sd).eval()
+        m.eval()
+        with torch.no_grad():
+            a, b = m(x), full(x)
+        for k in ('cls_logits', 'ordinal_logits', 'mu', 'log_var', 'kan_severity', 'features'):
+            # same kernels for backbone and KAN; the standalone heads sum their dot products in another order than the batched launch
+            assert float((a[k] - b[k]).abs().max()) < 1e-5, k
+    cfg = SimpleNamespace(train=SimpleNamespace(learning_rate=5e-4, weight_decay=1e-4, epochs=4), flags=SimpleNamespace(gradient_clip=1.0))
+    opt = build_optimizer(m, cfg)
+    loss_fn = JointLoss(1.0, 0.5, 0.5, 2.0, focal_alpha=torch.ones(4, device=dev()), num_classes=4)
+    stage = 4 if variant == 'full' else (3 if variant == 'no_kan' else 1)
+    m.train()
+    losses = []
+    for step in range(6):
+        if step == 0:
+            m.freeze_backbone()
+        if step == 1:
+            m.unfreeze_backbone()
+        out = m(x)
+        loss = loss_fn(out, y, y, stage)['total_loss']
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            assert all(p.grad is None for p in m.backbone.parameters())
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and min(losses[3:]) < losses[0], losses

@@ -307,6 +307,18 @@ def test_gradcam_and_attention_hooks_fire_from_the_fused_path_with_oracle_values
     # their bf16-staged input, so rounding error is amplified (measured cosine 0.985, uniform ~17 % per row); parameter
     # gradients average this out over rows (tests/test_gpu_model.py: cosine > 0.999)
     assert a_err < 6e-2 and cosg > 0.97 and g_err < 0.3 * g_scale
+
+    # the Grad-CAM++ map itself (gradcam.py:62-95, before the resize to 224 x 224) from both pairs of taps
+    def cam_map(gradients, activations):
+        alpha_num = gradients.pow(2)
+        alpha_den = 2 * gradients.pow(2) + (activations * gradients.pow(3)).sum(dim=1, keepdim=True)
+        alpha = alpha_num / torch.where(alpha_den != 0.0, alpha_den, torch.ones_like(alpha_den))
+        weights = (alpha * torch.relu(gradients)).sum(dim=2, keepdim=True)
+        return torch.relu((weights * activations).sum(dim=2)[:, 1:].reshape(14, 14))
+    cam_h, cam_r = cam_map(cap['grad'].cpu(), cap['act'].cpu()), cam_map(gref, taps['y'].detach())
+    cc = float(torch.corrcoef(torch.stack([cam_h.flatten(), cam_r.flatten()]))[0, 1])
+    print(f'Grad-CAM++ map: correlation with the oracle map {cc:.4f}, same hottest patch: {int(cam_h.argmax()) == int(cam_r.argmax())}')
+    assert cc > 0.99 and int(cam_h.argmax()) == int(cam_r.argmax())
     # hooks on blocks[i].attn see the attention module's output (B,197,192), as get_attention_maps returns it
     seen = []
     hooks = [b.attn.register_forward_hook(lambda mod, inp, outp: seen.append(outp.detach())) for b in m.backbone.model.blocks]

@@ -72,6 +72,34 @@ def test_kan_module_vs_reference_golden(golden_dir, name):
         assert float((p.grad.cpu() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max())), k
 
 
+def test_kan_visualisation_helpers_match_the_reference_formulas():
+    """KANLayer.plot_activation / get_spline_weights and KANSeverityModule.get_spline_weights (models/kan.py:96-114,151), what
+    explainability/kan_viz.py:22-36,184 draws: y(x) = sum_k basis_k(x) W[in, out, k] on linspace(-1, 1, n) WITHOUT tanh, zero
+    from the cutoff knot on."""
+    from models.kan import KANSeverityModule
+    g = torch.Generator().manual_seed(9)
+    sd = ref_cpu.init_kan_state([16, 8, 1], 5, 3, g)
+    m = KANSeverityModule([16, 8, 1], 5, 3)
+    m.load_state_dict(sd)
+    m = m.to(dev())
+    layer = m.kan_layers[0]
+    for i, o, n in ((0, 0, 100), (3, 5, 41), (15, 7, 7)):
+        xs, ys = layer.plot_activation(i, o, n)
+        xr = torch.linspace(-1, 1, n)
+        basis = ref_cpu.truncated_bspline_basis(xr.unsqueeze(0), sd['kan_layers.0.knots'], 3)[0]
+        yr = (basis * sd['kan_layers.0.spline_weights'][i, o]).sum(dim=1)
+        assert xs.shape == (n,) and np.allclose(xs, xr.numpy()) and np.abs(ys - yr.numpy()).max() < 1e-6
+        assert np.all(ys[xs >= ref_cpu_cut(sd)] == 0.0)
+    w = layer.get_spline_weights()
+    assert not w.requires_grad and torch.equal(w.cpu(), sd['kan_layers.0.spline_weights'])
+    assert [tuple(t.shape) for t in m.get_spline_weights()] == [(16, 8, 7), (8, 1, 7)]
+
+
+def ref_cpu_cut(sd):
+    k = sd['kan_layers.0.knots']
+    return float(k[k.numel() - 4])          # knots[num_basis]: the basis is identically zero from here on
+
+
 def test_kan_large_batch_vs_oracle():
     """BASELINE config 5 shape: grid_size=32, 3 stacked layers, batch 512."""
     from models.kan import KANSeverityModule

@@ -55,19 +55,13 @@ class RoViTAdamW(torch.optim.Optimizer):
         self.vit = model.backbone.model
         self.engine = self.vit.engine
         self.bb_params = self.vit.ordered_parameters()
-        dev = self.bb_params[0].device
-        if dev.type != 'cuda':
-            raise native.RovitHipError('RoViTAdamW needs the model on a CUDA/HIP device (call model.to(device) first)')
         if any(p.numel() % 4 for p in self.bb_params):
             raise native.RovitHipError('backbone parameters are expected to be multiples of 4 floats (16-byte aligned views)')
-        bb_offsets, o = [], 0
+        self._bb_offsets, o = [], 0
         for p in self.bb_params:
-            bb_offsets.append(o)
+            self._bb_offsets.append(o)
             o += p.numel()
-        self.p_flat = self._rehome(self.bb_params, bb_offsets, o, dev)
-        self.m_flat = torch.zeros_like(self.p_flat)
-        self.v_flat = torch.zeros_like(self.p_flat)
-        self.t = 0
+        self._bb_total = o
         # head / KAN parameters: one segment per top-level module, segment starts padded to 4 floats (16 bytes)
         groups = {}
         for n, p in model.named_parameters():
@@ -78,8 +72,37 @@ class RoViTAdamW(torch.optim.Optimizer):
         for name, ps in groups.items():
             self.segments.append(_Segment(name, ps, off))
             off += self.segments[-1].numel
+        self._o_total = max(off, 4)
         self.other_params = [p for s in self.segments for p in s.params]
-        self.o_flat = torch.zeros(max(off, 4), dtype=torch.float32, device=dev)
+        self.t = 0
+        self.p_flat = self.m_flat = self.v_flat = self.o_flat = self.o_grad = self.o_m = self.o_v = None
+        self._pending_flat = None
+        super().__init__([{'params': list(self.bb_params), 'lr': lr / 10.0}, {'params': list(self.other_params), 'lr': lr}],
+                         dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.last_grad_norm: Optional[torch.Tensor] = None
+        # The reference builds its optimizer BEFORE Trainer.__init__ moves the model to the device (scripts/train.py:104 vs
+        # training/trainer.py:32): the flat buffers are therefore created when the parameters are first seen on a
+        # CUDA/HIP device -- here if they already are, else at the first step / state_dict call -- and again if the model
+        # is moved afterwards (moments are carried over).
+        if self.bb_params[0].device.type == 'cuda':
+            self._build()
+
+    def _stale(self) -> bool:
+        p0 = self.bb_params[0]
+        return self.p_flat is None or p0.device != self.p_flat.device or p0.data_ptr() != self.p_flat.data_ptr()
+
+    def _build(self):
+        dev = self.bb_params[0].device
+        if dev.type != 'cuda':
+            raise native.RovitHipError('RoViTAdamW needs the model on a CUDA/HIP device before the first step '
+                                       '(model.to(device); building the optimizer earlier is fine)')
+        if any(p.device != dev for p in list(self.bb_params) + self.other_params):
+            raise native.RovitHipError('RoViTAdamW: all parameters must live on one device')
+        old = None if self.p_flat is None else (self.m_flat, self.v_flat, self.o_m, self.o_v)
+        self.p_flat = self._rehome(self.bb_params, self._bb_offsets, self._bb_total, dev)
+        self.m_flat = torch.zeros_like(self.p_flat)
+        self.v_flat = torch.zeros_like(self.p_flat)
+        self.o_flat = torch.zeros(self._o_total, dtype=torch.float32, device=dev)
         for s in self.segments:
             self._rehome(s.params, s.offsets, s.numel, dev, self.o_flat)
         self.o_grad = torch.zeros_like(self.o_flat)
@@ -87,13 +110,19 @@ class RoViTAdamW(torch.optim.Optimizer):
             s.grad_views = [self.o_grad[o:o + p.numel()].view_as(p) for o, p in zip(s.offsets, s.params)]
         self.o_m = torch.zeros_like(self.o_flat)
         self.o_v = torch.zeros_like(self.o_flat)
-        super().__init__([{'params': list(self.bb_params), 'lr': lr / 10.0}, {'params': list(self.other_params), 'lr': lr}],
-                         dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if old is not None:                                  # the model was moved after the buffers existed: keep the moments
+            for dst, src in zip((self.m_flat, self.v_flat, self.o_m, self.o_v), old):
+                dst.copy_(src)
         self._sq = torch.zeros((), dtype=torch.float32, device=dev)
         self._sq_scratch = torch.zeros(520, dtype=torch.float32, device=dev)     # fixed-order block partials (bit-reproducible norm)
         self._coef = torch.ones((), dtype=torch.float32, device=dev)
         self._norm = torch.zeros((), dtype=torch.float32, device=dev)
-        self.last_grad_norm: Optional[torch.Tensor] = None
+        self.engine._prep_key = None
+        if hasattr(self.model, 'kan_module') and hasattr(self.model.kan_module, 'invalidate_prepared'):
+            self.model.kan_module.invalidate_prepared()
+        if self._pending_flat is not None:
+            flat, self._pending_flat = self._pending_flat, None
+            self._load_flat(flat)
 
     @staticmethod
     def _rehome(params, offsets, total, dev, flat=None):
@@ -132,6 +161,10 @@ class RoViTAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self._stale():
+            if any(p.grad is not None for p in self.bb_params) and self.p_flat is not None:
+                raise native.RovitHipError('the model was moved between backward and optimizer.step(): run the step again')
+            self._build()
         eng = self.engine
         gb, gh = self.param_groups[0], self.param_groups[1]
         sp = stream_ptr()
@@ -183,19 +216,30 @@ class RoViTAdamW(torch.optim.Optimizer):
     def state_dict(self):
         """param_groups as torch reports them + the flat moment buffers and step counts."""
         sd = super().state_dict()
+        if self.p_flat is None:                              # nothing stepped yet (optimizer built before model.to(device))
+            sd['rovit_flat'] = self._pending_flat
+            return sd
         sd['rovit_flat'] = {'m_flat': self.m_flat.clone(), 'v_flat': self.v_flat.clone(), 'o_m': self.o_m.clone(),
                             'o_v': self.o_v.clone(), 't': self.t, 'segment_t': {s.name: s.t for s in self.segments}}
         return sd
+
+    def _load_flat(self, flat):
+        self.m_flat.copy_(flat['m_flat']); self.v_flat.copy_(flat['v_flat'])
+        self.o_m.copy_(flat['o_m']); self.o_v.copy_(flat['o_v'])
+        self.t = int(flat['t'])
+        for s in self.segments:
+            s.t = int(flat['segment_t'].get(s.name, 0))
 
     def load_state_dict(self, state_dict):
         flat = state_dict.get('rovit_flat')
         super().load_state_dict({k: v for k, v in state_dict.items() if k != 'rovit_flat'})
         if flat is not None:
-            self.m_flat.copy_(flat['m_flat']); self.v_flat.copy_(flat['v_flat'])
-            self.o_m.copy_(flat['o_m']); self.o_v.copy_(flat['o_v'])
-            self.t = int(flat['t'])
-            for s in self.segments:
-                s.t = int(flat['segment_t'].get(s.name, 0))
+            if self.p_flat is None and self.bb_params[0].device.type != 'cuda':
+                self._pending_flat = flat                    # applied when the buffers are built on the device
+                return
+            if self._stale():
+                self._build()
+            self._load_flat(flat)
 
 
 def build_optimizer(model, config) -> RoViTAdamW:

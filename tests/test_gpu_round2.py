@@ -862,3 +862,59 @@ def test_ablation_shaped_composition_of_standalone_modules_trains(variant):
         opt.step()
         losses.append(float(loss.detach()))
     assert all(np.isfinite(losses)) and min(losses[3:]) < losses[0], losses
+
+
+def test_optimizer_built_before_the_model_moves_to_the_device_like_scripts_train():
+    """scripts/train.py:104 builds the optimizer on the freshly constructed (CPU) model; training/trainer.py:32 moves the model to
+    the device afterwards.  The drop-in optimizer creates its flat buffers when it first sees the parameters on the device:
+    that order must train exactly like model.to(device) -> build_optimizer, survive a later .to() and a checkpoint round trip."""
+    from types import SimpleNamespace
+    from models.rovit_kan import RoViTKAN
+    from rovit_hip.losses import JointLoss
+    from rovit_hip.optim import build_optimizer, build_scheduler
+    cfg = SimpleNamespace(train=SimpleNamespace(learning_rate=3e-4, weight_decay=1e-4, epochs=3), flags=SimpleNamespace(gradient_clip=1.0))
+    sd = ref_cpu.init_rovit_state(seed=12)
+    x = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(4)).to(dev())
+    y = torch.randint(0, 4, (8,), generator=torch.Generator().manual_seed(5)).to(dev())
+    loss_fn = JointLoss(1.0, 0.5, 0.5, 2.0, focal_alpha=torch.ones(4, device=dev()), num_classes=4)
+
+    def run(order):
+        m = RoViTKAN(pretrained=False)
+        m.load_state_dict(sd)
+        if order == 'reference':                       # optimizer (and scheduler) first, on the CPU model; Trainer moves it later
+            opt = build_optimizer(m, cfg)
+            sched = build_scheduler(opt, cfg)
+            assert opt.state_dict()['rovit_flat'] is None
+            m = m.to(dev())
+        else:
+            m = m.to(dev())
+            opt = build_optimizer(m, cfg)
+            sched = build_scheduler(opt, cfg)
+        m.eval()                                       # no dropout: the two orders must agree bit for bit
+        losses = []
+        for _ in range(3):
+            loss = loss_fn(m(x), y, y, 4)['total_loss']
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            sched.step()
+            losses.append(float(loss.detach()))
+        return m, opt, losses
+
+    m_ref, opt_ref, l_ref = run('reference')
+    m_dev, opt_dev, l_dev = run('device-first')
+    assert l_ref == l_dev and l_ref[-1] < l_ref[0]
+    for (k, a), (_, b) in zip(m_ref.state_dict().items(), m_dev.state_dict().items()):
+        assert torch.equal(a, b), k
+    # checkpoint round trip into an optimizer that has not seen the device yet (resume before Trainer.__init__)
+    ck = {'model': {k: v.cpu() for k, v in m_ref.state_dict().items()}, 'opt': opt_ref.state_dict()}
+    m2 = RoViTKAN(pretrained=False)
+    m2.load_state_dict(ck['model'])
+    opt2 = build_optimizer(m2, cfg)
+    opt2.load_state_dict(ck['opt'])
+    m2 = m2.to(dev()).eval()
+    for mm, oo in ((m_ref, opt_ref), (m2, opt2)):
+        loss = loss_fn(mm(x), y, y, 4)['total_loss']
+        oo.zero_grad(); loss.backward(); oo.step()
+    for (k, a), (_, b) in zip(m_ref.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k

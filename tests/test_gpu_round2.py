@@ -908,6 +908,11 @@ def test_optimizer_built_before_the_model_moves_to_the_device_like_scripts_train
         assert torch.equal(a, b), k
     # checkpoint round trip into an optimizer that has not seen the device yet (resume before Trainer.__init__)
     ck = {'model': {k: v.cpu() for k, v in m_ref.state_dict().items()}, 'opt': opt_ref.state_dict()}
+    import io
+    buf = io.BytesIO()
+    torch.save(ck, buf)                                # Trainer.save_checkpoint / load_checkpoint (trainer.py:311-333)
+    buf.seek(0)
+    ck = torch.load(buf, map_location='cpu', weights_only=True)        # nothing but tensors, numbers and strings inside
     m2 = RoViTKAN(pretrained=False)
     m2.load_state_dict(ck['model'])
     opt2 = build_optimizer(m2, cfg)

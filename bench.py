@@ -326,7 +326,7 @@ def main():
     model.curriculum_stage = 4
     opt = RoViTAdamW(model, lr=1e-4, weight_decay=1e-4, max_grad_norm=1.0)   # clip_grad_norm_(1.0) + AdamW, backbone at lr/10
     loss_fn = JointLoss(1.0, 0.5, 0.5, 2.0, torch.ones(4, device=dev))
-    sync = GradSync(model, buckets=args.buckets, force=force_dist)
+    sync = GradSync(model, buckets=args.buckets, force=force_dist, optimizer=opt)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     images = torch.randn(args.batch, 3, 224, 224, device=dev, generator=g)
     labels = torch.randint(0, 4, (args.batch,), device=dev, generator=g)

@@ -139,7 +139,8 @@ class RoViTAdamW(torch.optim.Optimizer):
 
     def _pack_grads(self) -> List[_Segment]:
         """Copy the active segments' gradients into o_grad (one multi-tensor copy for all of them; the padding floats
-        between parameters are never written and stay zero)."""
+        between parameters are never written and stay zero).  A gradient that already IS its view of o_grad
+        (pack_and_install_grads ran, e.g. for the data-parallel bucket) is not copied again."""
         active, dst, src = [], [], []
         for s in self.segments:
             grads = [p.grad for p in s.params]
@@ -148,12 +149,34 @@ class RoViTAdamW(torch.optim.Optimizer):
             for v, g in zip(s.grad_views, grads):
                 if g is None:
                     v.zero_()
-                else:
+                elif g.data_ptr() != v.data_ptr():
                     dst.append(v); src.append(g)
             active.append(s)
         if dst:
             torch._foreach_copy_(dst, src)
         return active
+
+    def grad_view_ptrs(self):
+        """Addresses of the o_grad views (cached per buffer): tells a packed gradient from a fresh autograd tensor."""
+        key = None if self.o_grad is None else self.o_grad.data_ptr()
+        if getattr(self, '_gvp_key', None) != key:
+            self._gvp = frozenset(v.data_ptr() for s in self.segments for v in s.grad_views)
+            self._gvp_key = key
+        return self._gvp
+
+    def pack_and_install_grads(self):
+        """Pack the head / KAN gradients into the flat o_grad buffer NOW and make every ``param.grad`` its view of that buffer,
+        so that a data-parallel all-reduce can run in place on contiguous slices (GradSync(optimizer=...)) and step() finds
+        the gradients already packed.  Returns the (offset, numel) runs of o_grad that hold live gradients."""
+        if self._stale():
+            self._build()
+        with torch.no_grad():
+            active = self._pack_grads()
+            for s in active:
+                for p, v in zip(s.params, s.grad_views):
+                    if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                        p.grad = v
+        return [(first.offset, last.offset + last.numel - first.offset) for first, last in self._runs(active)]
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -391,6 +391,25 @@ def test_bucketed_grad_sync_one_rank_matches_plain_backward():
         assert len(sync.reducer.issued) == 4                       # 3 backbone buckets + heads
         for n, p in m.named_parameters():
             assert torch.equal(p.grad, g_plain[n]), n
+        # with the optimizer attached the head / KAN bucket is the optimizer's own flat gradient buffer, reduced in place:
+        # param.grad become views of it, the values stay those of the plain backward, and step() does not pack again
+        from rovit_hip.optim import RoViTAdamW
+        opt = RoViTAdamW(m, lr=1e-4)
+        sync2 = GradSync(m, buckets=2, force=True, optimizer=opt)
+        for p in m.parameters():
+            p.grad = None
+        lf(m(x), y, y, 4)['total_loss'].backward()
+        sync2.finish()
+        torch.cuda.synchronize()
+        assert len(sync2.reducer.issued) == 3                      # 2 backbone buckets + one contiguous head/KAN run
+        packed = opt.grad_view_ptrs()
+        for n, p in m.named_parameters():
+            assert torch.equal(p.grad, g_plain[n]), n
+            if not n.startswith('backbone.'):
+                assert p.grad.data_ptr() in packed, n
+        before = {n: p.detach().clone() for n, p in m.named_parameters()}
+        opt.step()
+        assert any(not torch.equal(before[n], p.detach()) for n, p in m.named_parameters())
     finally:
         eng = m.backbone.model.engine
         eng.backward_ranges = eng.range_hook = eng.notify_stream = None

@@ -923,3 +923,41 @@ def test_optimizer_built_before_the_model_moves_to_the_device_like_scripts_train
         oo.zero_grad(); loss.backward(); oo.step()
     for (k, a), (_, b) in zip(m_ref.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_large_batches_and_inference_mode():
+    """Batch 1024 (M = 201 728 rows: four times the benchmark batch; index arithmetic, grid sizing, workspace planning) gives,
+    image for image, the outputs of 256-image calls and -- training mode off, dropout off -- the parameter gradients of the
+    summed chunks; torch.inference_mode() is accepted like torch.no_grad()."""
+    sd = ref_cpu.init_rovit_state(depth=2, seed=77)
+    from models.rovit_kan import RoViTKAN
+    from models.backbone import DeiTTiny
+    m = RoViTKAN(pretrained=False)
+    m.backbone.model = DeiTTiny(depth=2)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev()).eval()
+    g = torch.Generator(device=dev()).manual_seed(1)
+    x = torch.randn(1024, 3, 224, 224, device=dev(), generator=g)
+    with torch.inference_mode():
+        big = m(x)
+    with torch.no_grad():
+        small = [m(x[i:i + 256]) for i in range(0, 1024, 256)]
+    for k in ('features', 'cls_logits', 'ordinal_logits', 'mu', 'log_var', 'kan_severity'):
+        assert torch.equal(big[k], torch.cat([s[k] for s in small])), k
+    w = torch.randn(1024, 192, device=dev(), generator=g)
+    for p in m.parameters():
+        p.grad = None
+    (m(x)['features'] * w).sum().backward()
+    g_big = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    acc = {}
+    for i in range(0, 1024, 256):
+        for p in m.parameters():
+            p.grad = None
+        (m(x[i:i + 256])['features'] * w[i:i + 256]).sum().backward()
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                acc[n] = acc.get(n, 0) + p.grad.double()
+    assert set(acc) == set(g_big)
+    for n in acc:
+        ref = acc[n].float()
+        assert float((g_big[n] - ref).abs().max()) < 2e-3 * float(ref.abs().max() + 1e-6), n

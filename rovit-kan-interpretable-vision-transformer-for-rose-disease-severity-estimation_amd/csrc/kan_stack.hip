@@ -125,7 +125,12 @@ __device__ __forceinline__ void ks_layer(const KanStackArgs& a, float* s_knots, 
     constexpr int XPF = TB * 16 / NT;
     f32x4 pw[PF], plw[LPF];
     float px[XPF];
-    const bool vec = ((nb * out_f * IC) & 3) == 0 && ((out_f * IC) & 3) == 0;   // 16-byte aligned chunk starts (host guarantees it)
+    // 16-byte copies need every chunk START (a multiple of IC features) and every chunk LENGTH (IC, and the short last chunk
+    // in_f % IC) to be whole float4s, for the slab and for the linear weights; any other shape takes the scalar copy
+    // (a final layer 6 -> 1 with 7 basis functions has 42 + 6 floats: the float4 copy would drop the last 2 + 2)
+    const int tail = in_f % IC;
+    const bool vec = ((nb * out_f * IC) & 3) == 0 && ((out_f * IC) & 3) == 0 &&
+                     (tail == 0 || (((nb * out_f * tail) & 3) == 0 && ((out_f * tail) & 3) == 0));
     if (vec) ks_prefetch<TB>(a, l, 0, IC, in_f, out_f, nb, b0, tid, pw, plw, px);
     for (int i0 = 0; i0 < in_f; i0 += IC) {
       const int ni = min(IC, in_f - i0);
@@ -603,6 +608,7 @@ extern "C" int rovit_kan_stack_fwd_mfma(const float* x, const float* const* wm, 
   // two sample tiles per wave halve the weight traffic through L2 but leave one wave per SIMD: pays when the MFMA phase
   // dominates and the batch still gives every SIMD a wave (G = 32 at batch 65536: 696 -> 618 us; G = 5: 186 -> 210 us, not used)
   static const int ns_env = getenv("ROVIT_KAN_MFMA_NS") ? atoi(getenv("ROVIT_KAN_MFMA_NS")) : 0;
+  ROVIT_CHECK_ARG(ns_env >= 0 && ns_env <= 2, ROVIT_ERR_SHAPE, "kan_stack_fwd_mfma: ROVIT_KAN_MFMA_NS must be 1 or 2 (got %d)", ns_env);
   const int ns = ns_env ? ns_env : ((H == 18 && batch >= 49152) ? 2 : 1);
   const int grid = (batch + KM_TS * ns - 1) / (KM_TS * ns);
   const size_t lds = (2 * KS_MAX_KNOTS + (size_t)2 * fpl * KM_TS * ns * 2 * H + (size_t)KM_TS * ns * (a.as0 + a.as1)) * sizeof(float);

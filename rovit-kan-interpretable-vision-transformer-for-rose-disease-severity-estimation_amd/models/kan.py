@@ -94,16 +94,26 @@ class KANSeverityModule(nn.Module):
                 wm = None
                 # the matrix-core kernel computes interval indices arithmetically: uniform grids only (kan.py:59 builds
                 # the knots with torch.linspace; a non-uniform buffer could only come from a hand-edited state_dict)
-                kn = l.knots.detach().float().cpu()
-                hstep = float(kn[-1] - kn[0]) / (kn.numel() - 1)
-                uniform = bool(((kn[1:] - kn[:-1]) - hstep).abs().max() <= 1e-4 * abs(hstep))
-                if nm and uniform:
+                if nm and self._uniform_knots(l):
                     wm = torch.empty(nm, device=w.device, dtype=torch.float32)
                     native.call('rovit_kan_prepare_mfma', native.ptr(w), native.ptr(lw), native.ptr(wm), l.in_features, l.out_features,
                                 l.num_basis, native.stream_ptr())
                 prep.append((wt, lwt, wm))
             self._prep, self._prep_key = prep, key
         return self._prep
+
+    def _uniform_knots(self, layer) -> bool:
+        """Knot uniformity is a property of a BUFFER the optimizer never touches: checked once per (storage, version) with one
+        device-to-host copy, not at every rebuild of the prepared weights (RoViTAdamW invalidates those every step)."""
+        cache = self.__dict__.setdefault('_uniform_cache', {})
+        key = (layer.knots.data_ptr(), layer.knots._version, str(layer.knots.device))
+        hit = cache.get(id(layer))
+        if hit is None or hit[0] != key:
+            kn = layer.knots.detach().float().cpu()
+            hstep = float(kn[-1] - kn[0]) / (kn.numel() - 1)
+            hit = (key, bool(((kn[1:] - kn[:-1]) - hstep).abs().max() <= 1e-4 * abs(hstep)))
+            cache[id(layer)] = hit
+        return hit[1]
 
     def invalidate_prepared(self):
         self._prep_key = None

@@ -355,6 +355,11 @@ class VitFn(torch.autograd.Function):
         ranges = engine.backward_ranges or [(depth - 1, 0)]
         hooked = engine.range_hook is not None and fresh
         grad_taps = ctx.grad_taps
+        if grad_taps and engine.range_hook is not None:
+            # the tapped backward is cut at the tapped blocks and does not hand its ranges to the reduction stream: the backbone
+            # gradients would stay rank-local and the replicas would drift apart without any error
+            raise native.RovitHipError('a Grad-CAM full-backward hook on blocks[i].norm1 cannot be combined with data-parallel '
+                                       'gradient sync (GradSync): run explainability passes on a model without GradSync')
         if grad_taps:
             # explainability taps: every tapped block ends a range of its own, so that its dqkv buffer can be read before
             # block-2 reuses it; the data-parallel notify path is not combined with taps

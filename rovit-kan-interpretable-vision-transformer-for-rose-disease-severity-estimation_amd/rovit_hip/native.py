@@ -15,6 +15,7 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get('ROVIT_HIP_LIB') or os.path.join(_PKG_ROOT, 'lib', 'librovit_hip.so')   # env override: developer A/B builds
 
 _lib: Optional[C.CDLL] = None
+ABI_VERSION = 300          # rovit_version() this binding matches (csrc/api.hip)
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -95,6 +96,9 @@ def load() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args
+        if lib.rovit_version() != ABI_VERSION:
+            raise RovitHipError(f'{LIB_PATH} has ABI version {lib.rovit_version()}, this binding was written for {ABI_VERSION}: '
+                                'rebuild the library (`make -C csrc`); argument lists changed between versions')
         _lib = lib
     return _lib
 

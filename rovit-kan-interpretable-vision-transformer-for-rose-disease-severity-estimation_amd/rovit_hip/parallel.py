@@ -129,6 +129,11 @@ class GradSync:
             for t in list(self.model.parameters()) + list(self.model.buffers()):
                 dist.broadcast(t.data, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         self.engine._prep_key = None          # bf16 weights must be re-prepared from the received values
+        # ... and so must the KAN module's prepared (transposed / matrix-core) layouts: `.data` writes do not bump _version
+        for m in self.model.modules():
+            if hasattr(m, 'invalidate_prepared'):
+                m.invalidate_prepared()
+                m.__dict__.pop('_uniform_cache', None)      # the knot buffers were broadcast too
 
     def slice_for(self, first: int, last: int) -> Tuple[int, int]:
         off = self.prefix + last * self.block_numel

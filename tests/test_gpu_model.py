@@ -17,8 +17,8 @@ pytestmark = pytest.mark.gpu
 
 from oracle import ref_cpu  # noqa: E402  (checker only)
 
-BF16_TOL = 5e-2
-BF16_RMS = 1.2e-2
+BF16_TOL = 3e-2          # ~1.5x the worst case measured on MI355X over rounds 1-2 (max-abs 1.3e-2 .. 2.1e-2)
+BF16_RMS = 8e-3          # measured RMS 4.3e-3 .. 6.1e-3
 
 
 def dev():

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import ref_cpu  # noqa: E402  (checker only)
 
-BF16_TOL = 5e-2          # stated bf16 tolerance of the backbone (max-abs on O(1) features / logits)
+BF16_TOL = 3e-2          # stated bf16 tolerance of the backbone (max-abs on O(1) features / logits)
 CLASS_NAMES = ["Healthy Leaf", "Leaf Holes", "Black Spot", "Dry Leaf"]
 SEVERITY = {n: i for i, n in enumerate(CLASS_NAMES)}
 
@@ -444,7 +444,10 @@ torch.save({'f': f.detach().cpu(), 'g': torch.cat([p.grad.flatten() for p in m.p
 
 
 @pytest.mark.parametrize('layers,num_knots,B', [([192, 64, 16, 1], 5, 8), ([192, 64, 16, 1], 5, 257), ([192, 64, 16, 1], 32, 512),
-                                                 ([16, 8, 1], 5, 33), ([24, 8, 1], 32, 16), ([192, 64, 16, 1], 5, 5000)])
+                                                 ([16, 8, 1], 5, 33), ([24, 8, 1], 32, 16), ([192, 64, 16, 1], 5, 5000),
+                                                 # widths whose slabs are NOT whole float4s (round-2 advisor finding: the 16-byte
+                                                 # chunk copy dropped the tail of a 6 -> 1 layer's 42 + 6 weights): scalar-copy path
+                                                 ([192, 6, 1], 5, 37), ([10, 1], 5, 19), ([18, 3, 1], 32, 9)])
 def test_fused_kan_stack_forward_equals_per_layer_kernels_and_oracle(layers, num_knots, B):
     """rovit_kan_stack_fwd (one launch, activations on chip, transposed W slabs in LDS) against the per-layer kernels
     (same arithmetic, different summation order over the input features) and against the CPU oracle, including every
@@ -492,7 +495,7 @@ def test_fused_kan_stack_forward_equals_per_layer_kernels_and_oracle(layers, num
             assert float((traj_m[i + 1] - h).abs().max()) < 2e-5, ('mfma', i)
         assert float((traj_m[-1].cpu() - ref_cpu.kan_module_forward(x, sd)).abs().max()) < 1e-4
     else:
-        assert layers[0] % 8 != 0              # the only parametrisation the matrix-core kernel does not cover
+        assert any(w % 8 != 0 for w in layers[:-1])   # the matrix-core kernel needs every layer's input width to be a multiple of 8
 
 
 def test_fp32_reference_precision_mode_meets_north_star_tolerances_end_to_end():
@@ -519,14 +522,19 @@ def test_fp32_reference_precision_mode_meets_north_star_tolerances_end_to_end():
     # a layer input within fp32 noise of the spline cutoff would still flip: count them (expected: none)
     xs_h = ref_cpu.kan_module_layer_inputs(out['features'], sd, 'kan_module.')
     xs_r = ref_cpu.kan_module_layer_inputs(ref['features'], sd, 'kan_module.')
-    flips = sum(int((((a >= ref_cpu.kan_cutoff(sd[f'kan_module.kan_layers.{li}.knots'])) !=
-                      (b >= ref_cpu.kan_cutoff(sd[f'kan_module.kan_layers.{li}.knots']))).any(1)).sum())
-                for li, (a, b) in enumerate(zip(xs_h, xs_r)))
+    flipped = torch.zeros(B, dtype=torch.bool)
+    for li, (a, b) in enumerate(zip(xs_h, xs_r)):
+        cut = ref_cpu.kan_cutoff(sd[f'kan_module.kan_layers.{li}.knots'])
+        flipped |= ((a >= cut) != (b >= cut)).any(1)
+    flips = int(flipped.sum())
     print('samples with a KAN input on opposite sides of the cutoff:', flips)
     for k in ('features', 'cls_logits', 'ordinal_logits', 'mu', 'log_var'):
         assert errs[k] < 1e-3, (k, errs[k])
-    if flips == 0:
-        assert errs['kan_severity'] < 1e-3, errs['kan_severity']
+    # kan_severity: 1e-3 on EVERY sample whose layer inputs sit on the same side of the spline cutoff in both paths (a flipped
+    # sample cannot be compared: SURVEY.md 0.2); the comparison never passes vacuously -- most samples must be comparable
+    assert flips <= B // 4, flips
+    sev_err = (out['kan_severity'] - ref['kan_severity']).abs().reshape(B)
+    assert float(sev_err[~flipped].max()) < 1e-3, sev_err
     assert torch.equal(out['cls_logits'].argmax(1), ref['cls_logits'].argmax(1))
     # the mode is inference-only and says so
     m.train()

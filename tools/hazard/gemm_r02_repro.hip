@@ -1,3 +1,6 @@
+// FROZEN COPY of csrc/gemm.hip as of round 2 (commit 4495d05) WITH the -DROVIT_HAZARD_REPRO=n variants of the residual+LayerNorm
+// epilogue that reproduce the packed-fp32 hazard (profiles/r02_hazard/).  Developer tooling only: the
+// product source csrc/gemm.hip carries none of these blocks any more.  Built by tools/hazard/build_variants.sh.
 // bf16 MFMA GEMMs for the DeiT-Tiny token matrix (M = B*197 rows, K/N in {192, 576, 768}).
 //
 //   gemm_nt   C[M,N] = A[M,K] * W[N,K]^T  (+ fused epilogue)       forward linears and dgrads
@@ -24,7 +27,7 @@
 // all output tiles of one M-split in wgrad) run on the same XCD and share that XCD's L2.
 #include <cstdlib>
 #include <type_traits>
-#include "common.h"
+#include "common.h"   // found through -I <package>/csrc (build_variants.sh)
 
 namespace {
 
@@ -336,6 +339,9 @@ __global__ __launch_bounds__(256 * WK, 2) void gemm_ws_kernel(const GemmArgs g, 
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bf16* Ac = As + (cur * BM + l15) * STR + wk * KS * 32 + lg * 8;
+#if defined(ROVIT_HAZARD_REPRO) && ROVIT_HAZARD_REPRO == 6
+    if (!(g.dbg & 2))      // tools/hazard: run the epilogue with no MFMA issued by any wave of the CU
+#endif
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       bf16x8 af[TM];
@@ -428,6 +434,44 @@ __global__ __launch_bounds__(256 * WK, 2) void gemm_ws_kernel(const GemmArgs g, 
               // address registers -- produced a wrong row sum in lanes 48-63 of a wave in ~15 % of launches at
               // M = 50432, on two different MI355X; see DESIGN.md "observed hazard".  tools/stress_ln.py and
               // tests/test_gpu_stress.py screen for it.)
+#ifdef ROVIT_HAZARD_REPRO
+              // tools/hazard: the round-1 epilogue that showed the intermittent wrong row sum (stores between the adds
+              // and the reduction), kept only to study it; never defined in the product build
+              float sum = 0.f;
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+                float4 x = xp[16 * i + c];
+                x.x += v[4 * i]; x.y += v[4 * i + 1]; x.z += v[4 * i + 2]; x.w += v[4 * i + 3];
+                xp[16 * i + c] = x;
+                v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+                sum += x.x + x.y + x.z + x.w;
+              }
+              if (g.out) {
+#if ROVIT_HAZARD_REPRO == 2
+                const float mean = row_sum16_dpp(sum) * (1.f / 192.f);
+#else
+                const float mean = wave_sum16(sum) * (1.f / 192.f);
+#endif
+                float qs = 0.f;
+#pragma unroll
+                for (int e = 0; e < 12; ++e) { v[e] -= mean; qs += v[e] * v[e]; }
+#if ROVIT_HAZARD_REPRO == 2
+                const float r = rsqrtf(row_sum16_dpp(qs) * (1.f / 192.f) + g.eps);
+#else
+                const float r = rsqrtf(wave_sum16(qs) * (1.f / 192.f) + g.eps);
+#endif
+                bf16x4* hp0 = (bf16x4*)(g.out + (size_t)m * g.ldo);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                  f32x4 t = {v[4 * i] * r, v[4 * i + 1] * r, v[4 * i + 2] * r, v[4 * i + 3] * r};
+                  hp0[16 * i + c] = pack4(t);
+                }
+                if (c == 0) g.rstd_out[m] = r;
+#if ROVIT_HAZARD_REPRO == 3
+                g.rstd_out[g.M + (size_t)m * 16 + c] = sum;      // diagnostic: this lane's partial sum (rstd_out holds 17 M floats)
+#endif
+              }
+#else
               float4 xs[3];
               float sum = 0.f;
 #pragma unroll
@@ -460,6 +504,7 @@ __global__ __launch_bounds__(256 * WK, 2) void gemm_ws_kernel(const GemmArgs g, 
 #pragma unroll
                 for (int i = 0; i < 3; ++i) xp[16 * i + c] = xs[i];
               }
+#endif
             } else {
               // LayerNorm backward behind a dgrad: v = dxhat row (affine already folded into the weight),
               // dX += rstd * (v - mean(v) - xhat * mean(v * xhat)); dXb = bf16(dX)
@@ -561,6 +606,9 @@ int launch_ws(const GemmArgs& g0, int epi, hipStream_t st) {
   constexpr int K = KS * 32 * WK;
   const size_t lds = (size_t)2 * BM * (K + 16) * sizeof(bf16) + (WK == 2 ? (size_t)2 * 8 * (BM / 16 / WK) * 3 * 64 * sizeof(f32x4) : 0) +
                      (size_t)BM * (192 + 8) * sizeof(bf16)
+#if defined(ROVIT_HAZARD_REPRO) && ROVIT_HAZARD_REPRO == 5
+                     + 81920          // tools/hazard: pad the request so that only ONE workgroup fits a CU
+#endif
       ;
   dim3 grid(P * g.n_tiles), block(256 * WK);
 #define LAUNCHW(E)                                                                                        \

@@ -172,6 +172,19 @@ int rovit_gemm_mlp_bwd(const void* dY, int ldy, const void* H, int ldh, const vo
  * norm(x)): xhat_out bf16 (M,192) and rstd_out (M) of the updated rows; xhat_out NULL = residual add only. */
 int rovit_gemm_resid_ln(const void* A, int lda, const void* W, int ldw, int M, int K, const float* bias, float* X, void* xhat_out,
                         float* rstd_out, float eps, rovit_stream_t stream);
+/* The MLP half of a block in ONE launch (round 3; timm Block: x = x + mlp(norm2(x)), then the next norm1 -- timm `Mlp` and
+ * `Block` reached through models/backbone.py:23-25):  X (M,192) += fc2(GELU(fc1(xhat2))) + biases, xhat_out / rstd_out = the
+ * LayerNorm of the updated rows (xhat_out NULL = residual add only).  act / dact (bf16 (M,768): GELU(pre) and GELU'(pre), what
+ * the backward needs) may both be NULL (inference: nothing is kept), or dact alone.  `wstream` is the weight image written
+ * by rovit_mlp_prepare_stream (rovit_mlp_stream_bytes() bytes) from w1f = the bf16 fc1 weight with the norm2 affine folded in
+ * (rovit_prep_weight's Wf, (768,192)) and w2 = the bf16 fc2 weight (192,768); b1 = the folded fc1 bias (768), b2 (192).
+ * act and dact are bit-identical to rovit_gemm_nt(ROVIT_EPI_GELU)'s outputs. */
+size_t rovit_mlp_stream_bytes(void);
+int rovit_mlp_prepare_stream(const void* w1f, const void* w2, void* wstream, rovit_stream_t stream);
+int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const float* b1, const float* b2, void* act, void* dact, float* X,
+                        void* xhat_out, float* rstd_out, float eps, int M, rovit_stream_t stream);
+/* developer knob (A/B timing): waves per workgroup of rovit_mlp_fused_fwd, 8 = one 256-row workgroup per CU, 4 = two 128-row ones */
+int rovit_set_mlp_waves(int waves);
 /* dgrad through a Linear that follows a LayerNorm, fused with that LayerNorm's backward:
  * dxhat = dY W^T;  dX += rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat));  dXb = bf16(dX) */
 int rovit_gemm_ln_bwd(const void* dY, int ldy, const void* W, int ldw, int M, int K, const void* xhat, const float* rstd, float* dX,

@@ -1,0 +1,358 @@
+// The MLP half of a DeiT-Tiny block in ONE launch (round 3):
+//
+//     X[m,:] += fc2( GELU( fc1( xhat2[m,:] ) ) ),   then the LayerNorm that follows the residual add (xhat_out, rstd_out)
+//
+// Reference arithmetic being restated: timm `Mlp` (fc1 192 -> 768, exact-erf GELU, fc2 768 -> 192) inside a pre-norm block and
+// the next block's norm1, reached through /root/reference/models/backbone.py:23-25.  Before this kernel
+// the half was two launches (fc1 + GELU writing `act` / `gelu'`, then fc2 + residual + LayerNorm re-reading `act`): 349 MB and
+// 107 us per block at batch 256; `act` (77.5 MB per block) is now never read back in the forward, and an inference call
+// writes neither `act` nor `gelu'`.
+//
+// Structure.  A workgroup (8 waves) owns 256 rows; wave w owns the two 16-row tiles w and w + 8 for the WHOLE chain, so no
+// activation ever crosses waves:
+//   * xhat2 fragments of the wave's 32 rows stay in registers (MFMA B operand, 48 registers);
+//   * the hidden dimension is walked in 24 chunks of 32 units.  Per chunk the wave computes pre^T[hidden][row] with the
+//     weights as the MFMA "A" operand (v_mfma_f32_16x16x32_bf16), applies GELU in registers, and the bf16 result IS the B
+//     operand of the fc2 product over that chunk: the rows of W1 inside a 16-row MFMA tile are PERMUTED by the weight
+//     preparation (tile a holds hidden units 8q + r, tile b 8q + 4 + r for accumulator row 4q + r), so that lane (row, q)
+//     ends up with the eight consecutive hidden units 8q .. 8q+7 of its row -- one 16-byte store each for `act` and
+//     `gelu'`, and the natural contraction order for fc2;
+//   * fc2 accumulates out^T[192][row] over the 24 chunks in 96 accumulator registers;
+//   * both weight matrices (590 KB of bf16: neither registers nor LDS hold them next to the tiles) are STREAMED per workgroup
+//     from L2 through a 3-slot LDS ring by LDS-DMA (global_load_lds_dwordx4): the preparation (rovit_mlp_prepare_stream)
+//     writes them as the exact LDS image, fragment-major -- chunk c = 24 pieces of 1 KB, piece = the 64 lanes' 16-byte MFMA
+//     A-fragments -- so the DMA is a linear copy and every fragment read is lane-linear (conflict-free ds_read_b128).  All
+//     workgroups walk the same stream in the same order: after the first reader of an XCD it is served by that XCD's L2;
+//   * completion is hand-counted: per chunk a wave issues 3 DMA pieces and S stores (buffer stores, so that rows beyond M
+//     are dropped by the bounds check and the COUNT is the same in every wave), vmcnt(3 + 2 S) leaves two chunks in flight;
+//     one barrier per chunk;
+//   * epilogue: bf16(out + bias) is staged in LDS (aliasing the ring) and a row-wise pass (16 lanes per row) adds it to the
+//     fp32 residual stream and computes the next LayerNorm, exactly the arithmetic of gemm_ws_kernel's EPI_RESID_LN epilogue.
+// fc1 sums in the same order as gemm_ws_dma_kernel<EPI_GELU> (same MFMA, same k order, bias as the initial accumulator), so
+// `act` and `gelu'` are BIT-IDENTICAL to the two-launch path; fc2 sums the hidden units in one chain instead of two halves
+// (the K = 768 kernel splits K over wave pairs), so X agrees to fp32 summation order (tests/test_gpu_round3.py).
+#include <cstdlib>
+#include "common.h"
+
+namespace {
+
+constexpr int D = 192, HID = 768, HC = 32, NCHUNK = HID / HC;
+constexpr int PIECE = 512;                    // bf16 elements of a 1 KB piece (64 lanes x 16 bytes)
+constexpr int CH_PIECES = 24;                 // 12 fc1 fragments (2 tiles x 6 k-steps) + 12 fc2 fragments (12 output tiles)
+constexpr int CH_ELEMS = CH_PIECES * PIECE;   // 24 KB per chunk
+constexpr int NSLOT = 3;
+constexpr int CSTR = 192 + 8;                 // staged output tile [ROWS][CSTR] bf16
+// NW waves per workgroup, 32 rows per wave.  NW = 8: one 256-row workgroup per CU (104 KB of LDS).  NW = 4: 128-row workgroups,
+// TWO per CU (76 KB each), which are not coupled by each other's barriers: one's GELU (VALU) and row-wise epilogue (HBM) run
+// beside the other's MFMA phases, at the price of streaming the weights through L2 twice per 256 rows.
+constexpr int region_elems(int nw) { return NSLOT * CH_ELEMS > 32 * nw * CSTR ? NSLOT * CH_ELEMS : 32 * nw * CSTR; }   // ring / staged tile (aliased)
+constexpr size_t lds_bytes(int nw) { return (size_t)region_elems(nw) * sizeof(bf16) + (HID + D) * sizeof(float); }
+
+struct MlpFwdArgs {
+  const bf16* xin;        // (M,192) xhat2
+  const bf16* wstream;    // rovit_mlp_prepare_stream image of this block's fc1 (LayerNorm affine folded) and fc2 weights
+  const float* b1;        // (768) folded fc1 bias
+  const float* b2;        // (192) fc2 bias
+  bf16* act;              // (M,768) gelu(pre)   (MODE >= 1)
+  bf16* dact;             // (M,768) gelu'(pre)  (MODE == 2)
+  float* X;               // (M,192) residual stream, updated in place
+  bf16* xhat;             // (M,192) next LayerNorm output, or NULL
+  float* rstd;            // (M)
+  float eps;
+  int M;
+};
+
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// MODE 0: inference (nothing kept), 1: keep act, 2: keep act and gelu'
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void mlp_fused_fwd_kernel(const MlpFwdArgs g) {
+  constexpr int S = 2 * MODE;                 // stores one wave issues per chunk
+  constexpr int ROWS = 32 * NW;               // rows per workgroup: wave w owns the 16-row tiles w and w + NW
+  constexpr int PW = CH_PIECES / NW;          // DMA pieces one wave issues per chunk
+  extern __shared__ __attribute__((aligned(16))) bf16 lds[];   // ONE array: ring[3][24 KB] / staged tile, then the two biases
+  float* s_bias = (float*)(lds + region_elems(NW));              // [768] b1, [192] b2
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int r0 = blockIdx.x * ROWS;
+
+  auto dma = [&](int chunk, int slot) {
+    const bf16* src = g.wstream + (size_t)chunk * CH_ELEMS + lane * 8;
+#pragma unroll
+    for (int q = 0; q < PW; ++q) {
+      const int piece = w + NW * q;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * PIECE),
+                                       (__attribute__((address_space(3))) void*)(lds + slot * CH_ELEMS + piece * PIECE), 16, 0, 0);
+    }
+  };
+  dma(0, 0);
+  dma(1, 1);
+
+  // biases -> LDS (240 float4)
+  if (tid < (HID + D) / 4) {
+    const float4 v = tid < HID / 4 ? ((const float4*)g.b1)[tid] : ((const float4*)g.b2)[tid - HID / 4];
+    ((float4*)s_bias)[tid] = v;
+  }
+  // this wave's rows: tile i holds rows r0 + 128 i + 16 w + l15 (clamped for the loads; stores are bounds-checked)
+  int mrow[2];
+  bf16x8 xf[2][6];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    mrow[i] = r0 + 16 * NW * i + 16 * w + l15;
+    const int mc = mrow[i] < g.M ? mrow[i] : g.M - 1;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) xf[i][ks] = *(const bf16x8*)(g.xin + (size_t)mc * D + ks * 32 + lg * 8);
+  }
+  // buffer resources for the kept activations: rows >= M fall outside num_records and are dropped by the hardware
+  __amdgpu_buffer_rsrc_t r_act, r_dact;
+  if (MODE >= 1) r_act = __builtin_amdgcn_make_buffer_rsrc((void*)g.act, 0, (int)((size_t)g.M * HID * 2), 0x00020000);
+  if (MODE == 2) r_dact = __builtin_amdgcn_make_buffer_rsrc((void*)g.dact, 0, (int)((size_t)g.M * HID * 2), 0x00020000);
+  unsigned soff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) soff[i] = (unsigned)mrow[i] * (HID * 2) + lg * 16;
+
+  f32x4 a2[12][2];
+#pragma unroll
+  for (int ot = 0; ot < 12; ++ot)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a2[ot][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // bias ds_writes retired before the first barrier
+  int slot = 0;
+#pragma unroll 1
+  for (int c = 0; c < NCHUNK; ++c) {
+    // chunk c has landed once at most the younger operations of THIS wave are outstanding.  Issue order per iteration:
+    // [DMA(c+2): PW] [stores(c): S]; DMA(0), DMA(1) in the prologue.
+    if (c == 0) wait_vm<PW>();
+    else if (c == 1) wait_vm<PW + S>();
+    else if (c < NCHUNK - 1) wait_vm<PW + 2 * S>();
+    else wait_vm<2 * S>();
+    __builtin_amdgcn_s_barrier();                             // every wave's pieces of chunk c are in; chunk c-1 fully consumed
+    asm volatile("" ::: "memory");
+    if (c + 2 < NCHUNK) dma(c + 2, slot == 0 ? 2 : slot - 1);   // (c + 2) % 3: the slot chunk c-1 used
+
+    const bf16* sb = lds + slot * CH_ELEMS + lane * 8;
+    // ---- fc1: pre^T[32 hidden][32 rows], bias as the initial accumulator ----
+    f32x4 a1[2][2];
+    {
+      const f32x4 ba = *(const f32x4*)(s_bias + c * HC + 8 * lg), bb = *(const f32x4*)(s_bias + c * HC + 8 * lg + 4);
+      a1[0][0] = ba; a1[0][1] = ba; a1[1][0] = bb; a1[1][1] = bb;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+      const bf16x8 wa = *(const bf16x8*)(sb + ks * PIECE), wb = *(const bf16x8*)(sb + (6 + ks) * PIECE);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a1[0][i] = mfma16(wa, xf[i][ks], a1[0][i]);
+        a1[1][i] = mfma16(wb, xf[i][ks], a1[1][i]);
+      }
+    }
+    // ---- GELU in registers: lane (row, q) holds hidden units 32 c + 8 q + {0..3} (tile a) and + {4..7} (tile b) ----
+    bf16x8 av[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float ga, gd;
+          gelu_and_grad((float)(bf16)a1[t][i][r], ga, gd);      // the two-launch path's GELU sees the bf16-staged pre-activation
+          av[i][4 * t + r] = (bf16)ga;
+          dv[i][4 * t + r] = (bf16)gd;
+        }
+    if (MODE >= 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, av[i]), r_act, soff[i] + c * (HC * 2), 0, 0);
+        if (MODE == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dv[i]), r_dact, soff[i] + c * (HC * 2), 0, 0);
+      }
+    }
+    // ---- fc2: out^T[192][32 rows] += W2[:, chunk] act^T ----
+#pragma unroll
+    for (int ot = 0; ot < 12; ++ot) {
+      const bf16x8 w2 = *(const bf16x8*)(sb + (12 + ot) * PIECE);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a2[ot][i] = mfma16(w2, av[i], a2[ot][i]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's reads of the slot are done before it reaches the next barrier
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+
+  // ---- epilogue: bf16(out + b2) staged in LDS (aliases the ring: every wave must have left the loop) ----
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  // Row-wise pass, 16 lanes per row (lane c16 holds elements {64 i + 4 c16 .. +3}), 8 passes of RP = 4 NW rows.  The residual rows of
+  // passes 0-3 are requested BEFORE the staging writes and those of passes 4-7 before passes 0-3 are processed, so that the
+  // pass is not a chain of eight dependent HBM round trips (the accumulators' 96 registers are free by then).
+  constexpr int RP = 4 * NW;
+  const int c16 = tid & 15, prow = tid >> 4;
+  auto xrow = [&](int pass) -> float4* {
+    const int m = r0 + pass * RP + prow;
+    return (float4*)(g.X + (size_t)(m < g.M ? m : g.M - 1) * D);
+  };
+  float4 xa[4][3], xb[4][3];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xa[p][i] = xrow(p)[16 * i + c16];
+  bf16* Cs = lds;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int ot = 0; ot < 12; ++ot) {
+      const f32x4 bb = *(const f32x4*)(s_bias + HID + 16 * ot + 4 * lg);
+      f32x4 v = a2[ot][i];
+      v[0] += bb[0]; v[1] += bb[1]; v[2] += bb[2]; v[3] += bb[3];
+      *(bf16x4*)(Cs + (16 * NW * i + 16 * w + l15) * CSTR + 16 * ot + 4 * lg) = pack4(v);
+    }
+  barrier_lds();
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xb[p][i] = xrow(4 + p)[16 * i + c16];
+  // X += branch; next LayerNorm.  All arithmetic first, all stores last (DESIGN.md "packed-fp32 hazard": the library also
+  // carries no packed-fp32 VALU instruction).
+  auto finish = [&](int pass, float4 (&xs)[3]) {
+    const int row = pass * RP + prow;
+    const int m = r0 + row;
+    float4* xp = xrow(pass);
+    float v[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const bf16x4 t = *(const bf16x4*)(Cs + row * CSTR + 64 * i + 4 * c16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * i + e] = (float)t[e];
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float4 x = xs[i];
+      x.x += v[4 * i]; x.y += v[4 * i + 1]; x.z += v[4 * i + 2]; x.w += v[4 * i + 3];
+      xs[i] = x;
+      v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+      sum += (x.x + x.y) + (x.z + x.w);
+    }
+    if (g.xhat) {
+      const float mean = wave_sum16(sum) * (1.f / 192.f);
+      float qs = 0.f;
+#pragma unroll
+      for (int e = 0; e < 12; ++e) { v[e] -= mean; qs += v[e] * v[e]; }
+      const float r = rsqrtf(wave_sum16(qs) * (1.f / 192.f) + g.eps);
+      bf16x4 hq[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        f32x4 t = {v[4 * i] * r, v[4 * i + 1] * r, v[4 * i + 2] * r, v[4 * i + 3] * r};
+        hq[i] = pack4(t);
+      }
+      if (m < g.M) {
+        bf16x4* hp = (bf16x4*)(g.xhat + (size_t)m * D);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xp[16 * i + c16] = xs[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) hp[16 * i + c16] = hq[i];
+        if (c16 == 0) g.rstd[m] = r;
+      }
+    } else if (m < g.M) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) xp[16 * i + c16] = xs[i];
+    }
+  };
+#pragma unroll
+  for (int p = 0; p < 4; ++p) finish(p, xa[p]);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) finish(4 + p, xb[p]);
+}
+
+// Weight stream of one block: chunk c (hidden units 32 c .. 32 c + 31) = 24 pieces of 64 x 16 bytes;
+//   piece 6 t + ks (t = 0, 1; ks = 0..5): lane (l15, lg) = W1f[32 c + 8 (l15 >> 2) + 4 t + (l15 & 3)][32 ks + 8 lg .. +7]
+//   piece 12 + ot  (ot = 0..11):         lane (l15, lg) = W2[16 ot + l15][32 c + 8 lg .. +7]
+struct MlpPrepArgs { const char* base; size_t blk0, stride, off_w1, off_w2, off_out; };
+__global__ __launch_bounds__(256) void mlp_stream_prep_kernel(const MlpPrepArgs a) {
+  const int blk = blockIdx.y;
+  const char* q = a.base + a.blk0 + (size_t)blk * a.stride;
+  const bf16* w1 = (const bf16*)(q + a.off_w1);
+  const bf16* w2 = (const bf16*)(q + a.off_w2);
+  bf16* out = (bf16*)(const_cast<char*>(q) + a.off_out);
+  const int e = blockIdx.x * 256 + threadIdx.x;          // 16-byte element of the stream: NCHUNK * 24 * 64
+  if (e >= NCHUNK * CH_PIECES * 64) return;
+  const int lane = e & 63, piece = (e >> 6) % CH_PIECES, c = e / (64 * CH_PIECES);
+  const int l15 = lane & 15, lg = lane >> 4;
+  const bf16* src;
+  if (piece < 12) {
+    const int t = piece / 6, ks = piece - 6 * t;
+    src = w1 + (size_t)(HC * c + 8 * (l15 >> 2) + 4 * t + (l15 & 3)) * D + 32 * ks + 8 * lg;
+  } else {
+    src = w2 + (size_t)(16 * (piece - 12) + l15) * HID + HC * c + 8 * lg;
+  }
+  *(bf16x8*)(out + (size_t)e * 8) = *(const bf16x8*)src;
+}
+
+}  // namespace
+
+// developer knob (A/B timing): waves per workgroup of the fused MLP forward, 8 (one 256-row workgroup per CU) or 4 (two 128-row
+// workgroups per CU); environment ROVIT_MLP_WAVES
+// (measured on MI355X, batch 256, training step: 8 waves 5.86 ms, 4 waves 5.97 ms, two-launch MLP half 5.96 ms)
+static int g_mlp_waves = [] { const char* e = getenv("ROVIT_MLP_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+extern "C" int rovit_set_mlp_waves(int nw) {
+  ROVIT_CHECK_ARG(nw == 4 || nw == 8, ROVIT_ERR_SHAPE, "set_mlp_waves: 4 or 8 (got %d)", nw);
+  g_mlp_waves = nw;
+  return ROVIT_OK;
+}
+
+extern "C" size_t rovit_mlp_stream_bytes(void) { return (size_t)NCHUNK * CH_ELEMS * sizeof(bf16); }
+
+// (internal) streams of `depth` blocks laid out inside the prepared-weight buffer of rovit_vit_prepare
+int rovit_mlp_stream_prep_blocks(const void* prep_base, size_t blk0, size_t stride, size_t off_w1, size_t off_w2, size_t off_out,
+                                 int depth, rovit_stream_t stream) {
+  const MlpPrepArgs a{(const char*)prep_base, blk0, stride, off_w1, off_w2, off_out};
+  hipLaunchKernelGGL(mlp_stream_prep_kernel, dim3(NCHUNK * CH_PIECES * 64 / 256, depth), dim3(256), 0, (hipStream_t)stream, a);
+  ROVIT_CHECK_LAUNCH("mlp_stream_prep_kernel");
+  return ROVIT_OK;
+}
+
+// w1f: bf16 (768,192) fc1 weight with the LayerNorm affine folded in (rovit_prep_weight's Wf); w2: bf16 (192,768) fc2 weight;
+// wstream: rovit_mlp_stream_bytes() bytes, 16-byte aligned.
+extern "C" int rovit_mlp_prepare_stream(const void* w1f, const void* w2, void* wstream, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(w1f && w2 && wstream, ROVIT_ERR_NULL, "mlp_prepare_stream: null pointer");
+  ROVIT_CHECK_ARG(rovit_aligned16(w1f) && rovit_aligned16(w2) && rovit_aligned16(wstream), ROVIT_ERR_ALIGN, "mlp_prepare_stream: alignment");
+  // one "block" whose three fields are addressed relative to w1f
+  const MlpPrepArgs a{(const char*)w1f, 0, 0, 0, (size_t)((const char*)w2 - (const char*)w1f), (size_t)((char*)wstream - (const char*)w1f)};
+  hipLaunchKernelGGL(mlp_stream_prep_kernel, dim3(NCHUNK * CH_PIECES * 64 / 256, 1), dim3(256), 0, (hipStream_t)stream, a);
+  ROVIT_CHECK_LAUNCH("mlp_stream_prep_kernel");
+  return ROVIT_OK;
+}
+
+// X(M,192) += fc2(GELU(fc1(xhat2))) and the LayerNorm behind it, one launch.  act / dact: NULL for inference (nothing kept);
+// dact alone may be NULL (gelu' recomputed by the backward).  xhat_out NULL: no LayerNorm.
+extern "C" int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const float* b1, const float* b2, void* act, void* dact,
+                                   float* X, void* xhat_out, float* rstd_out, float eps, int M, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(xhat2 && wstream && b1 && b2 && X, ROVIT_ERR_NULL, "mlp_fused_fwd: null pointer");
+  ROVIT_CHECK_ARG(M > 0 && (size_t)M * HID * 2 < ((size_t)1 << 31), ROVIT_ERR_SHAPE, "mlp_fused_fwd: M = %d out of range", M);
+  ROVIT_CHECK_ARG(act || !dact, ROVIT_ERR_NULL, "mlp_fused_fwd: dact without act");
+  ROVIT_CHECK_ARG(!xhat_out || rstd_out, ROVIT_ERR_NULL, "mlp_fused_fwd: rstd_out missing");
+  ROVIT_CHECK_ARG(rovit_aligned16(xhat2) && rovit_aligned16(wstream) && rovit_aligned16(b1) && rovit_aligned16(b2) && rovit_aligned16(X) &&
+                      rovit_aligned16(act) && rovit_aligned16(dact) && rovit_aligned16(xhat_out),
+                  ROVIT_ERR_ALIGN, "mlp_fused_fwd: buffers must be 16-byte aligned");
+  const MlpFwdArgs g{(const bf16*)xhat2, (const bf16*)wstream, b1, b2, (bf16*)act, (bf16*)dact, X, (bf16*)xhat_out, rstd_out, eps, M};
+  hipStream_t st = (hipStream_t)stream;
+  const int nw = g_mlp_waves;
+  const dim3 grid((M + 32 * nw - 1) / (32 * nw)), block(64 * nw);
+#define LAUNCH_MODE(MD, NWV)                                                                                                     \
+  do {                                                                                                                           \
+    ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_fwd_kernel<MD, NWV>, lds_bytes(NWV)), ROVIT_ERR_LAUNCH,             \
+                    "mlp_fused_fwd: cannot raise the LDS limit");                                                                \
+    hipLaunchKernelGGL((mlp_fused_fwd_kernel<MD, NWV>), grid, block, lds_bytes(NWV), st, g);                                     \
+  } while (0)
+  if (nw == 8) {
+    if (!act) LAUNCH_MODE(0, 8); else if (!dact) LAUNCH_MODE(1, 8); else LAUNCH_MODE(2, 8);
+  } else {
+    if (!act) LAUNCH_MODE(0, 4); else if (!dact) LAUNCH_MODE(1, 4); else LAUNCH_MODE(2, 4);
+  }
+#undef LAUNCH_MODE
+  ROVIT_CHECK_LAUNCH("mlp_fused_fwd_kernel");
+  return ROVIT_OK;
+}

@@ -40,6 +40,7 @@ struct Prep {          // byte offsets into the prepared-weight buffer
   size_t wpe;
   size_t blk0, blk_stride;
   size_t wqkv, wqkvT, wproj, wprojT, wfc1, wfc1T, wfc2, wfc2T, bqkv, bfc1;   // offsets inside one block
+  size_t wmlp;            // fc1 + fc2 as the weight stream of the fused MLP forward (mlp_fused.hip)
   size_t total;
   explicit Prep(int depth) {
     size_t o = 0;
@@ -56,6 +57,7 @@ struct Prep {          // byte offsets into the prepared-weight buffer
     wfc2T = b; b = al(b + (size_t)MLP * D * 2);
     bqkv = b; b = al(b + (size_t)3 * D * 4);
     bfc1 = b; b = al(b + (size_t)MLP * 4);
+    wmlp = b; b = al(b + rovit_mlp_stream_bytes());
     blk_stride = b;
     total = blk0 + (size_t)depth * blk_stride;
   }
@@ -229,6 +231,7 @@ extern "C" int rovit_vit_prepare(const float* const* params, void* prep, int dep
     descs.push_back({bp[B_FC2W], nullptr, nullptr, nullptr, q + P.wfc2, q + P.wfc2T, nullptr, D, MLP});
   }
   RUN(rovit_prep_weight_batch(descs.data(), (int)descs.size(), stream));
+  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc1, P.wfc2, P.wmlp, depth, stream));
   return ROVIT_OK;
 }
 
@@ -318,6 +321,21 @@ int vit_forward_impl(const float* images, const float* const* params, const void
         RUN(rovit_gemm_resid_ln(ROWS(s + L.o, D, 2), D, q + P.wproj, D, h.nb * T, D, bp[B_PROJB], Xh, ROWS(s + L.xhat2, D, 2),
                                 (float*)ROWS(s + L.rstd2, 1, 4), eps, h.st));
       }
+    }
+    // MLP half: one launch (fc1 + GELU + fc2 + residual + next LayerNorm, mlp_fused.hip); `act` is never re-read, and an
+    // inference call keeps neither act nor gelu'.  ROVIT_MLP_FUSED=0: the two-launch path (A/B timing).
+    static const bool mlp_fused = !(getenv("ROVIT_MLP_FUSED") && getenv("ROVIT_MLP_FUSED")[0] == '0');
+    if (mlp_fused && !cls_only) {
+      char* sn = ws + L.blk0 + (size_t)(i + 1) * L.blk_stride;            // next block's saved-activation area
+      EACH_HALF {
+        const Half& h = halves[hh];
+        float* Xh = X + (size_t)h.b0 * T * D;
+        RUN(rovit_mlp_fused_fwd(ROWS(s + L.xhat2, D, 2), q + P.wmlp, (const float*)(q + P.bfc1), bp[B_FC2B],
+                                training ? ROWS(s + L.act, MLP, 2) : nullptr,
+                                (training && !recompute_gelu()) ? ROWS(s + L.dact, MLP, 2) : nullptr, Xh, ROWS(sn + L.xhat1, D, 2),
+                                (float*)ROWS(sn + L.rstd1, 1, 4), eps, h.nb * T, h.st));
+      }
+      continue;
     }
     EACH_HALF {
       const Half& h = halves[hh];

@@ -50,6 +50,10 @@ SIGNATURES = {
     'rovit_gemm_nt': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     'rovit_gemm_mlp_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     'rovit_gemm_resid_ln': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp]),
+    'rovit_mlp_stream_bytes': (_sz, []),
+    'rovit_mlp_prepare_stream': (_i, [_vp, _vp, _vp, _vp]),
+    'rovit_mlp_fused_fwd': (_i, [_vp] * 9 + [_f, _i, _vp]),
+    'rovit_set_mlp_waves': (_i, [_i]),
     'rovit_gemm_ln_bwd': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'rovit_set_gemm_tile': (_i, [_i]),
     'rovit_set_gemm_debug': (_i, [_i]),

@@ -183,6 +183,12 @@ size_t rovit_mlp_stream_bytes(void);
 int rovit_mlp_prepare_stream(const void* w1f, const void* w2, void* wstream, rovit_stream_t stream);
 int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const float* b1, const float* b2, void* act, void* dact, float* X,
                         void* xhat_out, float* rstd_out, float eps, int M, rovit_stream_t stream);
+/* The dgrad chain of the same half in ONE launch (autograd of the above, training/trainer.py:119,136):
+ *   dpre (M,768) = (dY (M,192) W2T^T) * dact        -- kept: the fc1 weight gradient reads it (bit-identical to rovit_gemm_nt(ROVIT_EPI_MUL))
+ *   dX (M,192) += rstd2 (g - mean(g) - xhat2 mean(g xhat2)),  g = dpre W1T^T;   dXb = bf16(dX)     (= rovit_gemm_ln_bwd)
+ * wstream_bwd: rovit_mlp_prepare_stream(w1f := W2T bf16 (768,192), w2 := W1T bf16 (192,768), norm2 affine folded in). */
+int rovit_mlp_fused_bwd(const void* dY, const void* wstream_bwd, const void* dact, void* dpre, const void* xhat2, const float* rstd2,
+                        float* dX, void* dXb, int M, rovit_stream_t stream);
 /* developer knob (A/B timing): waves per workgroup of rovit_mlp_fused_fwd, 8 = one 256-row workgroup per CU, 4 = two 128-row ones */
 int rovit_set_mlp_waves(int waves);
 /* dgrad through a Linear that follows a LayerNorm, fused with that LayerNorm's backward:

@@ -28,6 +28,13 @@
 //     one barrier per chunk;
 //   * epilogue: bf16(out + bias) is staged in LDS (aliasing the ring) and a row-wise pass (16 lanes per row) adds it to the
 //     fp32 residual stream and computes the next LayerNorm, exactly the arithmetic of gemm_ws_kernel's EPI_RESID_LN epilogue.
+// BACKWARD (round 3, same skeleton, KIND = 1): the dgrad chain of the MLP half in one launch,
+//     dpre = (dY W2T^T) * gelu'(pre)   [kept: the fc1 weight gradient needs it]      dxhat2 = dpre W1T^T
+//     dX += rstd2 (dxhat2 - mean(dxhat2) - xhat2 mean(dxhat2 xhat2)),  dXb = bf16(dX)        (LayerNorm-2 backward)
+// i.e. rovit_gemm_nt(EPI_MUL) + rovit_gemm_ln_bwd without re-reading dpre (77.5 MB per block at batch 256).  The stream is the
+// same image built from (W2T, W1T) instead of (W1, W2); the gelu' tile of a chunk (each wave's own two 16 x 32 pieces) comes
+// in through the SAME ring by LDS-DMA with a per-lane source address (a register load inside the loop would make the compiler
+// wait vmcnt(0) and drain the ring), and `x gelu'` replaces GELU.  dpre is bit-identical to the two-launch path.
 // fc1 sums in the same order as gemm_ws_dma_kernel<EPI_GELU> (same MFMA, same k order, bias as the initial accumulator), so
 // `act` and `gelu'` are BIT-IDENTICAL to the two-launch path; fc2 sums the hidden units in one chain instead of two halves
 // (the K = 768 kernel splits K over wave pairs), so X agrees to fp32 summation order (tests/test_gpu_round3.py).
@@ -38,26 +45,30 @@ namespace {
 
 constexpr int D = 192, HID = 768, HC = 32, NCHUNK = HID / HC;
 constexpr int PIECE = 512;                    // bf16 elements of a 1 KB piece (64 lanes x 16 bytes)
-constexpr int CH_PIECES = 24;                 // 12 fc1 fragments (2 tiles x 6 k-steps) + 12 fc2 fragments (12 output tiles)
-constexpr int CH_ELEMS = CH_PIECES * PIECE;   // 24 KB per chunk
+constexpr int CH_PIECES = 24;                 // 12 first-GEMM fragments (2 tiles x 6 k-steps) + 12 second-GEMM fragments (12 output tiles)
+constexpr int CH_ELEMS = CH_PIECES * PIECE;   // 24 KB of weights per chunk
 constexpr int NSLOT = 3;
 constexpr int CSTR = 192 + 8;                 // staged output tile [ROWS][CSTR] bf16
-// NW waves per workgroup, 32 rows per wave.  NW = 8: one 256-row workgroup per CU (104 KB of LDS).  NW = 4: 128-row workgroups,
-// TWO per CU (76 KB each), which are not coupled by each other's barriers: one's GELU (VALU) and row-wise epilogue (HBM) run
-// beside the other's MFMA phases, at the price of streaming the weights through L2 twice per 256 rows.
-constexpr int region_elems(int nw) { return NSLOT * CH_ELEMS > 32 * nw * CSTR ? NSLOT * CH_ELEMS : 32 * nw * CSTR; }   // ring / staged tile (aliased)
-constexpr size_t lds_bytes(int nw) { return (size_t)region_elems(nw) * sizeof(bf16) + (HID + D) * sizeof(float); }
+// NW waves per workgroup, 32 rows per wave.  NW = 8: one 256-row workgroup per CU.  NW = 4 (forward only): 128-row workgroups,
+// two per CU (76 KB each).  A backward slot also holds the workgroup's gelu' tile of the chunk (2 NW pieces).
+constexpr int slot_elems(int kind, int nw) { return CH_ELEMS + (kind ? 2 * nw * PIECE : 0); }
+constexpr int region_elems(int kind, int nw) {      // ring / staged tile (aliased)
+  return NSLOT * slot_elems(kind, nw) > 32 * nw * CSTR ? NSLOT * slot_elems(kind, nw) : 32 * nw * CSTR;
+}
+constexpr size_t lds_bytes(int kind, int nw) { return (size_t)region_elems(kind, nw) * sizeof(bf16) + (HID + D) * sizeof(float); }
 
-struct MlpFwdArgs {
-  const bf16* xin;        // (M,192) xhat2
-  const bf16* wstream;    // rovit_mlp_prepare_stream image of this block's fc1 (LayerNorm affine folded) and fc2 weights
-  const float* b1;        // (768) folded fc1 bias
-  const float* b2;        // (192) fc2 bias
-  bf16* act;              // (M,768) gelu(pre)   (MODE >= 1)
-  bf16* dact;             // (M,768) gelu'(pre)  (MODE == 2)
-  float* X;               // (M,192) residual stream, updated in place
-  bf16* xhat;             // (M,192) next LayerNorm output, or NULL
-  float* rstd;            // (M)
+struct MlpArgs {
+  const bf16* xin;        // (M,192): forward xhat2, backward dY (gradient w.r.t. the MLP output)
+  const bf16* wstream;    // rovit_mlp_prepare_stream image: forward (W1 folded, W2), backward (W2T, W1T folded)
+  const float* b1;        // forward: (768) folded fc1 bias
+  const float* b2;        // forward: (192) fc2 bias
+  bf16* act;              // forward (M,768) gelu(pre) (MODE >= 1); backward (M,768) dpre (output)
+  bf16* dact;             // forward (M,768) gelu'(pre) (MODE == 2)
+  const bf16* mul;        // backward (M,768) gelu'(pre)
+  float* X;               // (M,192) forward: residual stream; backward: dX; updated in place
+  bf16* xhat;             // forward: next LayerNorm output or NULL; backward: xhat2 (input)
+  float* rstd;            // forward: (M) output; backward: rstd2 (input)
+  bf16* xb;               // backward: (M,192) bf16 copy of the updated dX
   float eps;
   int M;
 };
@@ -67,46 +78,54 @@ typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// MODE 0: inference (nothing kept), 1: keep act, 2: keep act and gelu'
-template <int MODE, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void mlp_fused_fwd_kernel(const MlpFwdArgs g) {
+// KIND 0 forward (MODE 0: inference, nothing kept; 1: keep act; 2: keep act and gelu'), KIND 1 backward (MODE 1: dpre kept)
+template <int KIND, int MODE, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) {
   constexpr int S = 2 * MODE;                 // stores one wave issues per chunk
   constexpr int ROWS = 32 * NW;               // rows per workgroup: wave w owns the 16-row tiles w and w + NW
-  constexpr int PW = CH_PIECES / NW;          // DMA pieces one wave issues per chunk
-  extern __shared__ __attribute__((aligned(16))) bf16 lds[];   // ONE array: ring[3][24 KB] / staged tile, then the two biases
-  float* s_bias = (float*)(lds + region_elems(NW));              // [768] b1, [192] b2
+  constexpr int PW = CH_PIECES / NW + (KIND ? 2 : 0);   // DMA pieces one wave issues per chunk
+  constexpr int SLOT = slot_elems(KIND, NW);
+  extern __shared__ __attribute__((aligned(16))) bf16 lds[];   // ONE array: ring / staged tile, then the two biases
+  float* s_bias = (float*)(lds + region_elems(KIND, NW));       // forward: [768] b1, [192] b2
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
   const int r0 = blockIdx.x * ROWS;
 
+  // this wave's rows: tile i holds rows r0 + 16 (w + NW i) + l15 (clamped for the loads; stores are bounds-checked)
+  int mrow[2], mcl[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    mrow[i] = r0 + 16 * NW * i + 16 * w + l15;
+    mcl[i] = mrow[i] < g.M ? mrow[i] : g.M - 1;
+  }
   auto dma = [&](int chunk, int slot) {
     const bf16* src = g.wstream + (size_t)chunk * CH_ELEMS + lane * 8;
 #pragma unroll
-    for (int q = 0; q < PW; ++q) {
+    for (int q = 0; q < CH_PIECES / NW; ++q) {
       const int piece = w + NW * q;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * PIECE),
-                                       (__attribute__((address_space(3))) void*)(lds + slot * CH_ELEMS + piece * PIECE), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(lds + slot * SLOT + piece * PIECE), 16, 0, 0);
+    }
+    if (KIND) {        // this wave's own gelu' pieces: lane (row l15, q = lg) <- gelu'[row][32 chunk + 8 q .. +7]
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.mul + (size_t)mcl[i] * HID + chunk * HC + lg * 8),
+                                         (__attribute__((address_space(3))) void*)(lds + slot * SLOT + (CH_PIECES + w + NW * i) * PIECE), 16, 0, 0);
     }
   };
   dma(0, 0);
   dma(1, 1);
 
-  // biases -> LDS (240 float4)
-  if (tid < (HID + D) / 4) {
+  if (!KIND && tid < (HID + D) / 4) {             // biases -> LDS (240 float4)
     const float4 v = tid < HID / 4 ? ((const float4*)g.b1)[tid] : ((const float4*)g.b2)[tid - HID / 4];
     ((float4*)s_bias)[tid] = v;
   }
-  // this wave's rows: tile i holds rows r0 + 128 i + 16 w + l15 (clamped for the loads; stores are bounds-checked)
-  int mrow[2];
   bf16x8 xf[2][6];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    mrow[i] = r0 + 16 * NW * i + 16 * w + l15;
-    const int mc = mrow[i] < g.M ? mrow[i] : g.M - 1;
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int ks = 0; ks < 6; ++ks) xf[i][ks] = *(const bf16x8*)(g.xin + (size_t)mc * D + ks * 32 + lg * 8);
-  }
+    for (int ks = 0; ks < 6; ++ks) xf[i][ks] = *(const bf16x8*)(g.xin + (size_t)mcl[i] * D + ks * 32 + lg * 8);
   // buffer resources for the kept activations: rows >= M fall outside num_records and are dropped by the hardware
   __amdgpu_buffer_rsrc_t r_act, r_dact;
   if (MODE >= 1) r_act = __builtin_amdgcn_make_buffer_rsrc((void*)g.act, 0, (int)((size_t)g.M * HID * 2), 0x00020000);
@@ -135,12 +154,14 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_fwd_kernel(const MlpFwdA
     asm volatile("" ::: "memory");
     if (c + 2 < NCHUNK) dma(c + 2, slot == 0 ? 2 : slot - 1);   // (c + 2) % 3: the slot chunk c-1 used
 
-    const bf16* sb = lds + slot * CH_ELEMS + lane * 8;
-    // ---- fc1: pre^T[32 hidden][32 rows], bias as the initial accumulator ----
+    const bf16* sb = lds + slot * SLOT + lane * 8;
+    // ---- first GEMM: pre^T (dgrad: g^T) [32 hidden][32 rows]; forward: bias as the initial accumulator ----
     f32x4 a1[2][2];
-    {
+    if (!KIND) {
       const f32x4 ba = *(const f32x4*)(s_bias + c * HC + 8 * lg), bb = *(const f32x4*)(s_bias + c * HC + 8 * lg + 4);
       a1[0][0] = ba; a1[0][1] = ba; a1[1][0] = bb; a1[1][1] = bb;
+    } else {
+      a1[0][0] = a1[0][1] = a1[1][0] = a1[1][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) {
@@ -151,19 +172,31 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_fwd_kernel(const MlpFwdA
         a1[1][i] = mfma16(wb, xf[i][ks], a1[1][i]);
       }
     }
-    // ---- GELU in registers: lane (row, q) holds hidden units 32 c + 8 q + {0..3} (tile a) and + {4..7} (tile b) ----
+    // ---- elementwise in registers: lane (row, q) holds hidden units 32 c + 8 q + {0..3} (tile a) and + {4..7} (tile b) ----
     bf16x8 av[2], dv[2];
+    if (!KIND) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float ga, gd;
-          gelu_and_grad((float)(bf16)a1[t][i][r], ga, gd);      // the two-launch path's GELU sees the bf16-staged pre-activation
-          av[i][4 * t + r] = (bf16)ga;
-          dv[i][4 * t + r] = (bf16)gd;
-        }
+          for (int r = 0; r < 4; ++r) {
+            float ga, gd;
+            gelu_and_grad((float)(bf16)a1[t][i][r], ga, gd);      // the two-launch path's GELU sees the bf16-staged pre-activation
+            av[i][4 * t + r] = (bf16)ga;
+            dv[i][4 * t + r] = (bf16)gd;
+          }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16x8 mf = *(const bf16x8*)(sb + (CH_PIECES + w + NW * i) * PIECE);      // this lane's own gelu' values
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)           // the two-launch path multiplies the bf16-staged dgrad by the bf16 mask in fp32
+            av[i][4 * t + r] = (bf16)((float)(bf16)a1[t][i][r] * (float)mf[4 * t + r]);
+      }
+    }
     if (MODE >= 1) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -171,7 +204,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_fwd_kernel(const MlpFwdA
         if (MODE == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dv[i]), r_dact, soff[i] + c * (HC * 2), 0, 0);
       }
     }
-    // ---- fc2: out^T[192][32 rows] += W2[:, chunk] act^T ----
+    // ---- second GEMM: out^T[192][32 rows] += W[:, chunk] act^T ----
 #pragma unroll
     for (int ot = 0; ot < 12; ++ot) {
       const bf16x8 w2 = *(const bf16x8*)(sb + (12 + ot) * PIECE);
@@ -182,7 +215,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_fwd_kernel(const MlpFwdA
     slot = slot == 2 ? 0 : slot + 1;
   }
 
-  // ---- epilogue: bf16(out + b2) staged in LDS (aliases the ring: every wave must have left the loop) ----
+  // ---- epilogue: bf16(out [+ b2]) staged in LDS (aliases the ring: every wave must have left the loop) ----
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   // Row-wise pass, 16 lanes per row (lane c16 holds elements {64 i + 4 c16 .. +3}), 8 passes of RP = 4 NW rows.  The residual rows of
@@ -190,42 +223,80 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_fwd_kernel(const MlpFwdA
   // pass is not a chain of eight dependent HBM round trips (the accumulators' 96 registers are free by then).
   constexpr int RP = 4 * NW;
   const int c16 = tid & 15, prow = tid >> 4;
-  auto xrow = [&](int pass) -> float4* {
-    const int m = r0 + pass * RP + prow;
-    return (float4*)(g.X + (size_t)(m < g.M ? m : g.M - 1) * D);
-  };
+  auto crow = [&](int pass) -> int { const int m = r0 + pass * RP + prow; return m < g.M ? m : g.M - 1; };
   float4 xa[4][3], xb[4][3];
+  bf16x4 ha[4][3], hb[4][3];       // backward: xhat2 rows
+  float ra[4], rb[4];              // backward: rstd2
+  auto fetch = [&](int pass, float4 (&xs)[3], bf16x4 (&hs)[3], float& rr) {
+    const int mc = crow(pass);
 #pragma unroll
-  for (int p = 0; p < 4; ++p)
+    for (int i = 0; i < 3; ++i) xs[i] = ((const float4*)(g.X + (size_t)mc * D))[16 * i + c16];
+    if (KIND) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) xa[p][i] = xrow(p)[16 * i + c16];
+      for (int i = 0; i < 3; ++i) hs[i] = ((const bf16x4*)(g.xhat + (size_t)mc * D))[16 * i + c16];
+      rr = g.rstd[mc];
+    }
+  };
+#pragma unroll
+  for (int p = 0; p < 4; ++p) fetch(p, xa[p], ha[p], ra[p]);
   bf16* Cs = lds;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int ot = 0; ot < 12; ++ot) {
-      const f32x4 bb = *(const f32x4*)(s_bias + HID + 16 * ot + 4 * lg);
       f32x4 v = a2[ot][i];
-      v[0] += bb[0]; v[1] += bb[1]; v[2] += bb[2]; v[3] += bb[3];
+      if (!KIND) {
+        const f32x4 bb = *(const f32x4*)(s_bias + HID + 16 * ot + 4 * lg);
+        v[0] += bb[0]; v[1] += bb[1]; v[2] += bb[2]; v[3] += bb[3];
+      }
       *(bf16x4*)(Cs + (16 * NW * i + 16 * w + l15) * CSTR + 16 * ot + 4 * lg) = pack4(v);
     }
   barrier_lds();
 #pragma unroll
-  for (int p = 0; p < 4; ++p)
-#pragma unroll
-    for (int i = 0; i < 3; ++i) xb[p][i] = xrow(4 + p)[16 * i + c16];
-  // X += branch; next LayerNorm.  All arithmetic first, all stores last (DESIGN.md "packed-fp32 hazard": the library also
-  // carries no packed-fp32 VALU instruction).
-  auto finish = [&](int pass, float4 (&xs)[3]) {
+  for (int p = 0; p < 4; ++p) fetch(4 + p, xb[p], hb[p], rb[p]);
+  // forward: X += branch; next LayerNorm.  backward: dX += LayerNorm-backward(dxhat); dXb = bf16(dX).  All arithmetic first, all
+  // stores last (DESIGN.md "packed-fp32 hazard": the library also carries no packed-fp32 VALU instruction).
+  auto finish = [&](int pass, float4 (&xs)[3], const bf16x4 (&hs)[3], float rr) {
     const int row = pass * RP + prow;
     const int m = r0 + row;
-    float4* xp = xrow(pass);
+    float4* xp = (float4*)(g.X + (size_t)crow(pass) * D);
     float v[12];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const bf16x4 t = *(const bf16x4*)(Cs + row * CSTR + 64 * i + 4 * c16);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[4 * i + e] = (float)t[e];
+    }
+    if (KIND) {
+      // dX += rstd (v - mean(v) - xhat mean(v xhat)); the affine is already folded into W1T (same arithmetic and summation
+      // order as gemm_ws_kernel's EPI_LNBWD epilogue)
+      float h[12];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h[4 * i + e] = (float)hs[i][e]; s1 += v[4 * i + e]; s2 += v[4 * i + e] * h[4 * i + e]; }
+      const float c1 = wave_sum16(s1) * (1.f / 192.f), c2 = wave_sum16(s2) * (1.f / 192.f);
+      bf16x4 bq[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float4 x = xs[i];
+        x.x += rr * (v[4 * i] - c1 - h[4 * i] * c2);
+        x.y += rr * (v[4 * i + 1] - c1 - h[4 * i + 1] * c2);
+        x.z += rr * (v[4 * i + 2] - c1 - h[4 * i + 2] * c2);
+        x.w += rr * (v[4 * i + 3] - c1 - h[4 * i + 3] * c2);
+        xs[i] = x;
+        f32x4 t = {x.x, x.y, x.z, x.w};
+        bq[i] = pack4(t);
+      }
+      if (m < g.M) {
+        bf16x4* bp = (bf16x4*)(g.xb + (size_t)m * D);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xp[16 * i + c16] = xs[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bp[16 * i + c16] = bq[i];
+      }
+      return;
     }
     float sum = 0.f;
 #pragma unroll
@@ -262,9 +333,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_fwd_kernel(const MlpFwdA
     }
   };
 #pragma unroll
-  for (int p = 0; p < 4; ++p) finish(p, xa[p]);
+  for (int p = 0; p < 4; ++p) finish(p, xa[p], ha[p], ra[p]);
 #pragma unroll
-  for (int p = 0; p < 4; ++p) finish(4 + p, xb[p]);
+  for (int p = 0; p < 4; ++p) finish(4 + p, xb[p], hb[p], rb[p]);
 }
 
 // Weight stream of one block: chunk c (hidden units 32 c .. 32 c + 31) = 24 pieces of 64 x 16 bytes;
@@ -337,15 +408,17 @@ extern "C" int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const
   ROVIT_CHECK_ARG(rovit_aligned16(xhat2) && rovit_aligned16(wstream) && rovit_aligned16(b1) && rovit_aligned16(b2) && rovit_aligned16(X) &&
                       rovit_aligned16(act) && rovit_aligned16(dact) && rovit_aligned16(xhat_out),
                   ROVIT_ERR_ALIGN, "mlp_fused_fwd: buffers must be 16-byte aligned");
-  const MlpFwdArgs g{(const bf16*)xhat2, (const bf16*)wstream, b1, b2, (bf16*)act, (bf16*)dact, X, (bf16*)xhat_out, rstd_out, eps, M};
+  MlpArgs g{};
+  g.xin = (const bf16*)xhat2; g.wstream = (const bf16*)wstream; g.b1 = b1; g.b2 = b2; g.act = (bf16*)act; g.dact = (bf16*)dact;
+  g.X = X; g.xhat = (bf16*)xhat_out; g.rstd = rstd_out; g.eps = eps; g.M = M;
   hipStream_t st = (hipStream_t)stream;
   const int nw = g_mlp_waves;
   const dim3 grid((M + 32 * nw - 1) / (32 * nw)), block(64 * nw);
 #define LAUNCH_MODE(MD, NWV)                                                                                                     \
   do {                                                                                                                           \
-    ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_fwd_kernel<MD, NWV>, lds_bytes(NWV)), ROVIT_ERR_LAUNCH,             \
+    ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<0, MD, NWV>, lds_bytes(0, NWV)), ROVIT_ERR_LAUNCH,           \
                     "mlp_fused_fwd: cannot raise the LDS limit");                                                                \
-    hipLaunchKernelGGL((mlp_fused_fwd_kernel<MD, NWV>), grid, block, lds_bytes(NWV), st, g);                                     \
+    hipLaunchKernelGGL((mlp_fused_kernel<0, MD, NWV>), grid, block, lds_bytes(0, NWV), st, g);                                   \
   } while (0)
   if (nw == 8) {
     if (!act) LAUNCH_MODE(0, 8); else if (!dact) LAUNCH_MODE(1, 8); else LAUNCH_MODE(2, 8);
@@ -353,6 +426,26 @@ extern "C" int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const
     if (!act) LAUNCH_MODE(0, 4); else if (!dact) LAUNCH_MODE(1, 4); else LAUNCH_MODE(2, 4);
   }
 #undef LAUNCH_MODE
-  ROVIT_CHECK_LAUNCH("mlp_fused_fwd_kernel");
+  ROVIT_CHECK_LAUNCH("mlp_fused_kernel (forward)");
+  return ROVIT_OK;
+}
+
+// The dgrad chain of the MLP half in one launch: dpre (M,768) = (dY W2T^T) * dact, kept for the fc1 weight gradient;
+// dX (M,192) += LayerNorm-2-backward(dpre W1T^T) with xhat2 / rstd2 of the forward; dXb = bf16(dX).  wstream_bwd: the image
+// rovit_mlp_prepare_stream builds from (w1f := W2T (768,192), w2 := W1T folded (192,768)).
+extern "C" int rovit_mlp_fused_bwd(const void* dY, const void* wstream_bwd, const void* dact, void* dpre, const void* xhat2,
+                                   const float* rstd2, float* dX, void* dXb, int M, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(dY && wstream_bwd && dact && dpre && xhat2 && rstd2 && dX && dXb, ROVIT_ERR_NULL, "mlp_fused_bwd: null pointer");
+  ROVIT_CHECK_ARG(M > 0 && (size_t)M * HID * 2 < ((size_t)1 << 31), ROVIT_ERR_SHAPE, "mlp_fused_bwd: M = %d out of range", M);
+  ROVIT_CHECK_ARG(rovit_aligned16(dY) && rovit_aligned16(wstream_bwd) && rovit_aligned16(dact) && rovit_aligned16(dpre) &&
+                      rovit_aligned16(xhat2) && rovit_aligned16(dX) && rovit_aligned16(dXb),
+                  ROVIT_ERR_ALIGN, "mlp_fused_bwd: buffers must be 16-byte aligned");
+  MlpArgs g{};
+  g.xin = (const bf16*)dY; g.wstream = (const bf16*)wstream_bwd; g.act = (bf16*)dpre; g.mul = (const bf16*)dact; g.X = dX;
+  g.xhat = (bf16*)const_cast<void*>(xhat2); g.rstd = const_cast<float*>(rstd2); g.xb = (bf16*)dXb; g.M = M;
+  ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<1, 1, 8>, lds_bytes(1, 8)), ROVIT_ERR_LAUNCH,
+                  "mlp_fused_bwd: cannot raise the LDS limit");
+  hipLaunchKernelGGL((mlp_fused_kernel<1, 1, 8>), dim3((M + 255) / 256), dim3(512), lds_bytes(1, 8), (hipStream_t)stream, g);
+  ROVIT_CHECK_LAUNCH("mlp_fused_kernel (backward)");
   return ROVIT_OK;
 }

@@ -40,7 +40,7 @@ struct Prep {          // byte offsets into the prepared-weight buffer
   size_t wpe;
   size_t blk0, blk_stride;
   size_t wqkv, wqkvT, wproj, wprojT, wfc1, wfc1T, wfc2, wfc2T, bqkv, bfc1;   // offsets inside one block
-  size_t wmlp;            // fc1 + fc2 as the weight stream of the fused MLP forward (mlp_fused.hip)
+  size_t wmlp, wmlpb;     // fc1 + fc2 as the weight streams of the fused MLP forward / backward (mlp_fused.hip)
   size_t total;
   explicit Prep(int depth) {
     size_t o = 0;
@@ -58,6 +58,7 @@ struct Prep {          // byte offsets into the prepared-weight buffer
     bqkv = b; b = al(b + (size_t)3 * D * 4);
     bfc1 = b; b = al(b + (size_t)MLP * 4);
     wmlp = b; b = al(b + rovit_mlp_stream_bytes());
+    wmlpb = b; b = al(b + rovit_mlp_stream_bytes());
     blk_stride = b;
     total = blk0 + (size_t)depth * blk_stride;
   }
@@ -232,6 +233,7 @@ extern "C" int rovit_vit_prepare(const float* const* params, void* prep, int dep
   }
   RUN(rovit_prep_weight_batch(descs.data(), (int)descs.size(), stream));
   RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc1, P.wfc2, P.wmlp, depth, stream));
+  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc2T, P.wfc1T, P.wmlpb, depth, stream));     // dgrad chain: (W2T, W1T)
   return ROVIT_OK;
 }
 
@@ -537,12 +539,19 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
     char* dq = ws + L.dqkv[p];
     char* xmid = ws + L.x1[p];
     if (ss && i + 2 < depth && ev_bdone[i + 2] && hipStreamWaitEvent(sA, ev_bdone[i + 2], 0) != hipSuccess) EVFAIL("event wait");
-    if (recompute_gelu())                                                                                            // A1
-      RUN(rovit_gemm_mlp_bwd(xin, D, s + L.xhat2, D, q + P.wfc2T, q + P.wfc1, (const float*)(q + P.bfc1), M, dp, MLP, sA));
-    else
-      RUN(rovit_gemm_nt(xin, D, q + P.wfc2T, D, M, MLP, D, nullptr, EPI_MUL, dp, MLP, nullptr, nullptr, 0, s + L.dact, MLP, nullptr, 0, sA));
-    // fc1 dgrad fused with the backward of norm2 (updates dX, writes its bf16 copy)
-    RUN(rovit_gemm_ln_bwd(dp, MLP, q + P.wfc1T, MLP, M, MLP, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmid, sA));            // A2
+    // A1 + A2 in one launch (mlp_fused.hip): fc2 dgrad x gelu' -> dpre (kept for B2), fc1 dgrad + norm2 backward without
+    // re-reading dpre.  ROVIT_MLP_BWD_FUSED=0: the two launches (A/B timing); the gelu'-recompute memory mode keeps them too.
+    static const bool mlp_bwd_fused = !(getenv("ROVIT_MLP_BWD_FUSED") && getenv("ROVIT_MLP_BWD_FUSED")[0] == '0');
+    if (mlp_bwd_fused && !recompute_gelu()) {
+      RUN(rovit_mlp_fused_bwd(xin, q + P.wmlpb, s + L.dact, dp, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmid, M, sA));
+    } else {
+      if (recompute_gelu())                                                                                            // A1
+        RUN(rovit_gemm_mlp_bwd(xin, D, s + L.xhat2, D, q + P.wfc2T, q + P.wfc1, (const float*)(q + P.bfc1), M, dp, MLP, sA));
+      else
+        RUN(rovit_gemm_nt(xin, D, q + P.wfc2T, D, M, MLP, D, nullptr, EPI_MUL, dp, MLP, nullptr, nullptr, 0, s + L.dact, MLP, nullptr, 0, sA));
+      // fc1 dgrad fused with the backward of norm2 (updates dX, writes its bf16 copy)
+      RUN(rovit_gemm_ln_bwd(dp, MLP, q + P.wfc1T, MLP, M, MLP, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmid, sA));            // A2
+    }
     if (ss && !hand_over(ss, sA, sB)) EVFAIL("event hand-over");                                                   // E_i
     if (merge) {
       RUN(issue_merged(i, pending, xin, dp, xmid));                                                                // B4(prev) B1 B2 B3, B5

@@ -132,6 +132,72 @@ def test_fused_mlp_half_is_run_to_run_identical_at_full_size():
             assert torch.equal(X, ref[0]) and torch.equal(h.view(torch.int16), ref[1].view(torch.int16)) and torch.equal(r, ref[2]), it
 
 
+@pytest.mark.parametrize('M', [1, 37, 256, 257, 1000, 197 * 12, 256 * 197])
+def test_fused_mlp_backward_equals_the_two_launch_dgrad_chain_and_a_torch_reference(M):
+    """rovit_mlp_fused_bwd = rovit_gemm_nt(EPI_MUL) + rovit_gemm_ln_bwd in one launch: dpre bit-identical (same MFMA chain, the
+    bf16-staged dgrad times the bf16 mask in fp32), dX to the fp32 summation order of the second GEMM (one chain over the 768
+    hidden units here, two half-sums in the K = 768 kernel), dXb = bf16(dX) exactly."""
+    native = _native()
+    g = torch.Generator(device='cpu').manual_seed(900 + M)
+    r = lambda *s: torch.randn(*s, generator=g)
+    dY = bf(r(M, 192)).to(dev())
+    w2t = bf(r(768, 192) * 0.05).to(dev())             # fc2 weight transposed (768,192)
+    w1t = bf(r(192, 768) * 0.05).to(dev())             # fc1 weight (affine folded) transposed (192,768)
+    dact = bf(torch.rand(M, 768, generator=g) * 1.2 - 0.1).to(dev())
+    xh = bf(r(M, 192)).to(dev())
+    rstd = (torch.rand(M, generator=g) + 0.5).to(dev())
+    dX0 = r(M, 192).to(dev())
+    p, sp = native.ptr, native.stream_ptr()
+    # two launches
+    dpre0 = torch.empty(M, 768, device=dev(), dtype=torch.bfloat16)
+    native.call('rovit_gemm_nt', p(dY), 192, p(w2t), 192, M, 768, 192, None, 3, p(dpre0), 768, None, None, 0, p(dact), 768, None, 0, sp)
+    dXa = dX0.clone()
+    dXba = torch.empty(M, 192, device=dev(), dtype=torch.bfloat16)
+    native.call('rovit_gemm_ln_bwd', p(dpre0), 768, p(w1t), 768, M, 768, p(xh), p(rstd), p(dXa), p(dXba), sp)
+    # one launch
+    ws = torch.empty(native.load().rovit_mlp_stream_bytes(), dtype=torch.uint8, device=dev())
+    native.call('rovit_mlp_prepare_stream', p(w2t), p(w1t), p(ws), sp)
+    dpre1 = torch.full((M, 768), float('nan'), device=dev(), dtype=torch.bfloat16)
+    dXb1 = torch.full((M, 192), float('nan'), device=dev(), dtype=torch.bfloat16)
+    dX1 = dX0.clone()
+    native.call('rovit_mlp_fused_bwd', p(dY), p(ws), p(dact), p(dpre1), p(xh), p(rstd), p(dX1), p(dXb1), M, sp)
+    assert torch.equal(dpre0.view(torch.int16), dpre1.view(torch.int16))
+    assert torch.equal(dXb1.view(torch.int16), bf(dX1).view(torch.int16))
+    gq = bf(dpre1.float() @ w1t.float().t()).float()                  # the second dgrad, rounded as the kernel stages it
+    h = xh.float()
+    ref = dX0 + rstd[:, None] * (gq - gq.mean(1, keepdim=True) - h * (gq * h).mean(1, keepdim=True))
+    ulp = 2 ** -7 * float(gq.abs().max() * rstd.max())                # one bf16 ulp of the staged dgrad, through the LayerNorm backward
+    assert float((dX1 - ref).abs().max()) < 2e-3 * float(ref.abs().max()) + ulp
+    assert float((dX1 - dXa).abs().max()) < 2 * ulp and float((dX1 - dXa).abs().mean()) < 2e-4
+    # plain fp32 reference of the first product
+    ref_dpre = (dY.float() @ w2t.float().t()) * dact.float()
+    assert float((dpre1.float() - ref_dpre).abs().max()) < 2e-2 * float(ref_dpre.abs().max())
+
+
+def test_fused_mlp_backward_is_run_to_run_identical_at_full_size():
+    native = _native()
+    M = 256 * 197
+    g = torch.Generator(device='cpu').manual_seed(4)
+    r = lambda *s: torch.randn(*s, generator=g)
+    dY, w2t, w1t = bf(r(M, 192)).to(dev()), bf(r(768, 192) * 0.05).to(dev()), bf(r(192, 768) * 0.05).to(dev())
+    dact, xh = bf(torch.rand(M, 768, generator=g)).to(dev()), bf(r(M, 192)).to(dev())
+    rstd, dX0 = (torch.rand(M, generator=g) + 0.5).to(dev()), r(M, 192).to(dev())
+    p, sp = native.ptr, native.stream_ptr()
+    ws = torch.empty(native.load().rovit_mlp_stream_bytes(), dtype=torch.uint8, device=dev())
+    native.call('rovit_mlp_prepare_stream', p(w2t), p(w1t), p(ws), sp)
+    ref = None
+    for it in range(20):
+        dpre = torch.empty(M, 768, device=dev(), dtype=torch.bfloat16)
+        dXb = torch.empty(M, 192, device=dev(), dtype=torch.bfloat16)
+        dX = dX0.clone()
+        native.call('rovit_mlp_fused_bwd', p(dY), p(ws), p(dact), p(dpre), p(xh), p(rstd), p(dX), p(dXb), M, sp)
+        if ref is None:
+            ref = (dpre.clone(), dX.clone(), dXb.clone())
+        else:
+            assert torch.equal(dpre.view(torch.int16), ref[0].view(torch.int16)) and torch.equal(dX, ref[1]), it
+            assert torch.equal(dXb.view(torch.int16), ref[2].view(torch.int16)), it
+
+
 def test_backbone_forward_with_the_fused_mlp_half_matches_the_two_launch_build_of_the_same_forward():
     """ROVIT_MLP_FUSED=0 (read once per process) selects the two-launch MLP half: run both in subprocesses on the same seeded
     weights and images, training workspaces, and compare features, every gradient and the saved act / gelu' of a block."""
@@ -161,7 +227,7 @@ torch.save({'f': f.detach().cpu(), 'g': g.cpu()}, out)
     with tempfile.TemporaryDirectory() as td:
         for mode in ('1', '0'):
             out = os.path.join(td, f'o{mode}.pt')
-            env = dict(os.environ, ROVIT_MLP_FUSED=mode)
+            env = dict(os.environ, ROVIT_MLP_FUSED=mode, ROVIT_MLP_BWD_FUSED=mode)
             subprocess.run([sys.executable, '-c', code, out, root, pkg], check=True, env=env, timeout=600)
             res[mode] = torch.load(out, weights_only=True)
     f1, f0 = res['1']['f'], res['0']['f']

@@ -49,6 +49,25 @@ def main():
         variants[f'fused_train_w{nw}'] = with_waves(nw, fused(2))
         variants[f'fused_act_only_w{nw}'] = with_waves(nw, fused(1))
         variants[f'fused_inference_w{nw}'] = with_waves(nw, fused(0))
+    # backward: fc2 dgrad x gelu' + fc1 dgrad + norm2 backward, two launches against rovit_mlp_fused_bwd
+    dY = torch.randn(M, 192, device=dev).to(bf)
+    w2t = (torch.randn(768, 192, device=dev) * 0.05).to(bf)
+    w1t = (torch.randn(192, 768, device=dev) * 0.05).to(bf)
+    dpre = torch.empty(M, 768, device=dev, dtype=bf)
+    dX = torch.randn(M, 192, device=dev)
+    dXb = torch.empty(M, 192, device=dev, dtype=bf)
+    wsb = torch.empty(lib.rovit_mlp_stream_bytes(), dtype=torch.uint8, device=dev)
+    native.call('rovit_mlp_prepare_stream', p(w2t), p(w1t), p(wsb), sp)
+    dact.uniform_(0, 1)
+
+    def bwd_two():
+        lib.rovit_gemm_nt(p(dY), 192, p(w2t), 192, M, 768, 192, None, 3, p(dpre), 768, None, None, 0, p(dact), 768, None, 0, sp)
+        lib.rovit_gemm_ln_bwd(p(dpre), 768, p(w1t), 768, M, 768, p(xhat), p(rstd), p(dX), p(dXb), sp)
+
+    def bwd_fused():
+        lib.rovit_mlp_fused_bwd(p(dY), p(wsb), p(dact), p(dpre), p(xhat), p(rstd), p(dX), p(dXb), M, sp)
+    variants['bwd_two_launch'] = bwd_two
+    variants['bwd_fused'] = bwd_fused
     st = torch.cuda.current_stream(dev)
 
     def timed(fn, iters=20):
@@ -75,6 +94,9 @@ def main():
         alg[f'fused_train_w{nw}'] = base + 2.0 * M * 768 * 2
         alg[f'fused_act_only_w{nw}'] = base + 2.0 * M * 768
         alg[f'fused_inference_w{nw}'] = base
+    bbase = 2.0 * M * 192 * 3 + 8.0 * M * 192 + 4.0 * M      # dY, xhat2, dXb; dX read + write; rstd
+    alg['bwd_two_launch'] = bbase + 2.0 * M * 768 * 3
+    alg['bwd_fused'] = bbase + 2.0 * M * 768 * 2
     out = {k: {'us_min': min(v), 'us_median': sorted(v)[len(v) // 2], 'us_all': v, 'algorithmic_MB': round(alg[k] / 1e6, 1),
                'TBps_at_median': round(alg[k] / (sorted(v)[len(v) // 2] * 1e-6) / 1e12, 2)} for k, v in res.items()}
     print(json.dumps({'M': M, **out}))

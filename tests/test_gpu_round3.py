@@ -198,6 +198,34 @@ def test_fused_mlp_backward_is_run_to_run_identical_at_full_size():
             assert torch.equal(dXb.view(torch.int16), ref[2].view(torch.int16)), it
 
 
+@pytest.mark.parametrize('B,Tk', [(1, 197), (2, 197), (5, 197), (3, 64), (2, 208), (4, 33), (7, 1), (260, 197)])
+def test_pipelined_attention_backward_is_bit_identical_to_the_staged_kernel(B, Tk):
+    """attn_bwd_pipe_kernel (persistent workgroups, tiles by LDS-DMA while the previous pass computes, padded rows masked through
+    lse = +inf instead of zero-filled tiles) runs the same two passes in the same order as attn_bwd_kernel: dQ, dK, dV must be
+    bit-identical, for ragged token counts, batches smaller and larger than the persistent grid, and over repeated launches."""
+    native = _native()
+    H = 3
+    torch.manual_seed(B * 1000 + Tk)
+    M = B * Tk
+    qkv = bf(torch.randn(M, 3 * H * 64, device=dev()))
+    dO = bf(torch.randn(M, H * 64, device=dev()))
+    o = torch.empty(M, H * 64, device=dev(), dtype=torch.bfloat16)
+    lse = torch.empty(B, H, Tk, device=dev())
+    p, sp = native.ptr, native.stream_ptr()
+    native.call('rovit_attention_fwd', p(qkv), p(o), p(lse), B, Tk, H, 64, 0.125, sp)
+    outs = {}
+    for pipe in (0, 1, 1):
+        native.call('rovit_set_attn_bwd_pipe', pipe)
+        dqkv = torch.full((M, 3 * H * 64), float('nan'), device=dev(), dtype=torch.bfloat16)
+        native.call('rovit_attention_bwd', p(qkv), p(o), p(lse), p(dO), p(dqkv), B, Tk, H, 64, 0.125, sp)
+        if pipe in outs:
+            assert torch.equal(outs[pipe].view(torch.int16), dqkv.view(torch.int16))       # run to run
+        outs[pipe] = dqkv
+    native.call('rovit_set_attn_bwd_pipe', 0)      # the library default
+    assert torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
 def test_backbone_forward_with_the_fused_mlp_half_matches_the_two_launch_build_of_the_same_forward():
     """ROVIT_MLP_FUSED=0 (read once per process) selects the two-launch MLP half: run both in subprocesses on the same seeded
     weights and images, training workspaces, and compare features, every gradient and the saved act / gelu' of a block."""

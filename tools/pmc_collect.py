@@ -12,6 +12,7 @@ import csv
 import glob
 import json
 import os
+import shutil
 import subprocess
 import sys
 
@@ -50,7 +51,19 @@ def run_pass(tag, counters):
     with open(os.path.join(OUT, tag + '.log'), 'w') as log:
         rc = subprocess.call(cmd, cwd='/tmp', env=env, stdout=log, stderr=subprocess.STDOUT)
     files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
-    return rc, (files[0] if files else None)
+    if not files:
+        return rc, None
+    # keep ONE compact copy next to the logs and drop rocprofv3's output tree (gpurun merges at most 64 MiB back)
+    keep = os.path.join(OUT, tag + '_counter_collection.csv')
+    cols = ('Dispatch_Id', 'Kernel_Name', 'Grid_Size', 'Counter_Name', 'Counter_Value')
+    with open(files[0]) as fin, open(keep, 'w', newline='') as fout:
+        wr = csv.writer(fout)
+        wr.writerow(cols)
+        for r in csv.DictReader(fin):
+            if any(sub in r['Kernel_Name'] for sub, _, _ in KERNELS):
+                wr.writerow([r.get('Dispatch_Id', ''), r['Kernel_Name'], r.get('Grid_Size', ''), r['Counter_Name'], r['Counter_Value']])
+    shutil.rmtree(d, ignore_errors=True)
+    return rc, keep
 
 
 def per_kernel(path, counter):

@@ -1664,9 +1664,10 @@ int rovit_wgrad_batch(const RovitWgradDesc* descs, int n, int M, int splits, rov
   // a lone problem (the qkv weight gradient flushed at the end of a data-parallel block range): 96 x 96 tiles give twice the
   // workgroups for the same 16 M-splits (96 -> 192); every element still sums the same rows in the same order, so the
   // result is bit-identical to the merged launch's
-  // developer knob ROVIT_WGRAD_MERGE_TN=64: 64 x 192 tiles (36 per M-split instead of 24, so 14 splits make 504 workgroups = two per
-  // CU on 252 CUs, where 16 x 24 = 384 leave half of the CUs with one workgroup and half with two)
-  static const int merge_tn = getenv("ROVIT_WGRAD_MERGE_TN") ? atoi(getenv("ROVIT_WGRAD_MERGE_TN")) : 96;
+  // 64 x 192 tiles (round 3): 36 tiles per M-split instead of 24, so 14 splits make 504 workgroups = two per CU on 252 CUs, where
+  // 16 x 24 = 384 left half of the CUs with one workgroup and half with two (the launch then lasts as long as the doubly loaded
+  // half), and two slabs fewer are written.  Step 5.61-5.66 -> 5.54-5.62 ms on the same box.  ROVIT_WGRAD_MERGE_TN=96: round 2's tiles.
+  static const int merge_tn = getenv("ROVIT_WGRAD_MERGE_TN") ? atoi(getenv("ROVIT_WGRAD_MERGE_TN")) : 64;
   if (n == 1 && g.p[0].K % 96 == 0) launch_wgrad<96, 96>(g, (hipStream_t)stream);
   else if (merge_tn == 64) {
     for (int j = 0; j < n; ++j) ROVIT_CHECK_ARG(descs[j].N % 64 == 0, ROVIT_ERR_SHAPE, "wgrad_batch: N %% 64 for 64-wide tiles");

@@ -21,7 +21,7 @@ OUT = os.path.join(ROOT, 'gpurun_out', 'pmc_r03')
 
 # (substring of rocprof's Kernel_Name, occurrence group ordered by first dispatch when the same kernel runs two shapes, key)
 KERNELS = [
-    ('wgrad_kernel<96, 192, false, false>', 0, 'wgrad_kernel<96,192,false>'),
+    ('wgrad_kernel<64, 192, false, false>', 0, 'wgrad_kernel<64,192,false>'),
     ('gemm_ws_dma_kernel<0>', 0, 'qkv_fwd'),
     ('gemm_ws_dma_kernel<0>', 1, 'proj_dgrad'),
     ('attn_fwd_kernel', 0, 'attention_fwd'),

@@ -333,27 +333,25 @@ def kan_fwd_bwd_roofline(dev, G, B, iters=30):
     acts = [ACT_RELU, ACT_RELU, ACT_SIGMOID3]
     fwd = [(ptr(ins[i]), ptr(l.spline_weights), ptr(l.knots), ptr(l.linear.weight), ptr(l.linear.bias), ptr(outs[i]), B, l.in_features,
             l.out_features, l.knots.numel(), acts[i], sp) for i, l in enumerate(m.kan_layers)]
-    gin = [dxs[i + 1] if i + 1 < n else gout for i in range(n)]       # gradient w.r.t. layer i's output
-    bwd = [(ptr(ins[i]), ptr(l.spline_weights), ptr(l.knots), ptr(l.linear.weight), ptr(outs[i]), ptr(gin[i]), ptr(dxs[i]), ptr(dws[i]),
-            ptr(dlw[i]), ptr(dlb[i]), B, l.in_features, l.out_features, l.knots.numel(), acts[i], 0, sp) for i, l in enumerate(m.kan_layers)]
-    fused_bwd = getattr(m, 'fused_backward_launch', None)          # one-launch backward, when the library has it (round 3)
-    run_bwd = fused_bwd(x, outs, gout, dxs, dws, dlw, dlb) if fused_bwd else None
+    import ctypes as C
+    from rovit_hip.native import ptr_array
+    arr = lambda xs: (C.c_int * len(xs))(*xs)
+    gz = [torch.empty(B, layers[l + 1], device=dev) for l in range(n)]
+    bargs = (ptr(x), ptr_array([l.spline_weights for l in m.kan_layers]), ptr_array([l.knots for l in m.kan_layers]),
+             ptr_array([l.linear.weight for l in m.kan_layers]), ptr_array(outs), ptr_array([None, None, gout]), ptr_array(gz), ptr(dxs[0]),
+             ptr_array(dws), ptr_array(dlw), ptr_array(dlb), B, arr(layers), arr([l.knots.numel() for l in m.kan_layers]), arr(acts), n, sp)
 
     def run():
         for r in fwd:
             lib.rovit_kan_layer_fwd(*r)
-        if run_bwd:
-            run_bwd()
-        else:
-            for r in reversed(bwd):
-                lib.rovit_kan_layer_bwd(*r)
+        lib.rovit_kan_stack_bwd(*bargs)
     ms = _event_avg_ms(dev, run, iters, per_launch=False)
     w_bytes = sum(a * b * nb + a * b + b for a, b in zip(layers[:-1], layers[1:])) * 4
     act_bytes = B * (layers[0] + 2 * sum(layers[1:-1]) + layers[-1]) * 4
     alg = float(3 * w_bytes + 3 * act_bytes)
     useful = 3 * 2.0 * B * sum(a * b * 5 for a, b in zip(layers[:-1], layers[1:]))
     gbs = alg / (ms * 1e-3) / 1e9
-    return {'bound': 'hbm', 'kernel': 'KAN stack forward (3 launches) + backward (%s), kernels only' % ('one launch' if run_bwd else '3 x 2 launches'),
+    return {'bound': 'hbm', 'kernel': 'KAN stack forward (3 launches) + backward (2 launches: rovit_kan_stack_bwd), kernels only',
             'num_knots': G, 'batch': B, 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 5),
             'avg_us': round(ms * 1e3, 2), 'algorithmic_bytes': alg, 'traffic': None,
             'useful_fp32_tflops': round(useful / (ms * 1e-3) / 1e12, 3), 'useful_frac_of_fp32_peak': round(useful / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5)}

@@ -57,6 +57,15 @@ int rovit_kan_layer_fwd(const float* x, const float* spline_w, const float* knot
 int rovit_kan_layer_bwd(const float* x, const float* spline_w, const float* knots, const float* lin_w, const float* out,
                         const float* grad_out, float* dx, float* d_spline_w, float* d_lin_w, float* d_lin_b, int batch,
                         int in_f, int out_f, int n_knots, int act, int accumulate_dx, rovit_stream_t stream);
+/* Backward of the whole KANSeverityModule stack in two launches (autograd of models/kan.py:138-149): the per-sample chain
+ * dL/dz_n -> dx_n -> ... -> dx_1 in one launch (writes dL/dz of every layer into gz[l] (batch, out_l) and dx), then the
+ * parameter gradients of ALL layers in one launch.  Host arrays of n_layers device pointers; grad_outs[l] = gradient w.r.t.
+ * layer l's output from outside the stack (NULL entries allowed, the last must be set); d_spline_w NULL = no parameter
+ * gradients; dx NULL = no input gradient.  Same arithmetic and summation order as rovit_kan_layer_bwd per layer. */
+int rovit_kan_stack_bwd(const float* x, const float* const* spline_w, const float* const* knots, const float* const* lin_w,
+                        const float* const* outs, const float* const* grad_outs, float* const* gz, float* dx, float* const* d_spline_w,
+                        float* const* d_lin_w, float* const* d_lin_b, int batch, const int* dims, const int* n_knots, const int* acts,
+                        int n_layers, rovit_stream_t stream);
 /* Prepared weight layouts of one KAN layer for rovit_kan_stack_fwd (re-run whenever the parameters change):
  * spline_w (in, out, nb) -> spline_wt (in, nb, out); lin_w (out, in) -> lin_wt (in, out). */
 int rovit_kan_prepare(const float* spline_w, const float* lin_w, float* spline_wt, float* lin_wt, int in_f, int out_f, int n_basis,

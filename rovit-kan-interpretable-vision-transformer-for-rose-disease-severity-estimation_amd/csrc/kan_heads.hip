@@ -501,6 +501,222 @@ int launch_lin_batch(Batch& pb, int n, const int* work, Kernel kern, const char*
   return ROVIT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward of the whole KAN stack in TWO launches (round 3; six before: a dx and a dW launch per layer).
+//   1. kan_stack_bwd_dx_kernel: the chain dL/dz_3 -> dx_3 -> dL/dz_2 -> ... -> dx_1 is local to a sample, so one workgroup
+//      walks all layers for its TB samples with the inter-layer gradients in LDS; it writes dL/dz of every layer (what the
+//      parameter gradients need) and the gradient w.r.t. the stack input.  Per layer the arithmetic and the summation order
+//      are those of kan_bwd_dx_kernel (four lanes share a (sample, feature) pair).
+//   2. kan_stack_bwd_dw_kernel: one workgroup per (layer, input feature) = 192 + 64 + 16 workgroups in one launch; the body of
+//      kan_bwd_dw_kernel reading dL/dz directly.
+// Reference: autograd of KANSeverityModule.forward (/root/reference/models/kan.py:138-149, KANLayer.forward :70-95) as
+// reached from training/trainer.py:119,136.
+// ---------------------------------------------------------------------------------------------
+constexpr int KB_MAX_LAYERS = 4;
+constexpr int KB_MAXW = 64;                 // widest layer output (and input of every layer but the first)
+struct KanStackBwdArgs {
+  const float* x; int B; int nl;
+  int dims[KB_MAX_LAYERS + 1];
+  int nk[KB_MAX_LAYERS];
+  int act[KB_MAX_LAYERS];
+  const float* W[KB_MAX_LAYERS];            // spline weights (in, out, nb): reference layout
+  const float* knots[KB_MAX_LAYERS];
+  const float* lw[KB_MAX_LAYERS];           // linear weight (out, in)
+  const float* y[KB_MAX_LAYERS];            // post-activation outputs (B, out)
+  const float* gy[KB_MAX_LAYERS];           // gradient w.r.t. each layer's output coming from OUTSIDE the stack (NULL: none)
+  float* gz[KB_MAX_LAYERS];                 // (B, out) dL/dz, written by the dx kernel, read by the dW kernel
+  float* dx;                                // (B, in_0) or NULL
+  float* dW[KB_MAX_LAYERS]; float* dlw[KB_MAX_LAYERS]; float* dlb[KB_MAX_LAYERS];
+  int bc[KB_MAX_LAYERS];                    // batch rows per LDS chunk of the dW kernel
+  int thr[KB_MAX_LAYERS];                   // working threads of a layer's dW workgroups (as rovit_kan_layer_bwd picks them)
+  int wg0[KB_MAX_LAYERS + 1];               // first workgroup of each layer in the dW launch
+};
+
+template <int L>
+__device__ __forceinline__ void kb_dx_layer(const KanStackBwdArgs& a, float* s_knots, float* s_gz, float* s_gin, float* s_gout, int b0,
+                                            int TB, int tid, int T) {
+  const int in_f = a.dims[L], out_f = a.dims[L + 1], nk = a.nk[L], nb = nk - 4;
+  __syncthreads();                                     // previous layer done with s_knots / s_gz; its s_gout (our s_gin) complete
+  if (tid < nk) s_knots[tid] = a.knots[L][tid];
+  for (int e = tid; e < TB * out_f; e += T) {
+    const int bl = e / out_f, o = e - bl * out_f, b = b0 + bl;
+    float gz = 0.f;
+    if (b < a.B) {
+      float g = (L + 1 < KB_MAX_LAYERS && L + 1 < a.nl) ? s_gin[bl * KB_MAXW + o] : 0.f;       // from the layer above (its dx)
+      if (a.gy[L]) g += a.gy[L][(size_t)b * out_f + o];
+      gz = act_grad(g, a.y[L][(size_t)b * out_f + o], a.act[L]);
+      a.gz[L][(size_t)b * out_f + o] = gz;
+    }
+    s_gz[e] = gz;
+  }
+  __syncthreads();
+  if (L == 0 && !a.dx) return;
+  const float* x = L == 0 ? a.x : a.y[L - 1];           // this layer's input
+  const float* W = a.W[L];
+  const float* lw = a.lw[L];
+  const float inv_h0 = 1.f / (s_knots[1] - s_knots[0]);
+  const int part = tid & 3;
+  for (int e0 = 0; e0 < TB * in_f; e0 += T / 4) {
+    const int e = e0 + (tid >> 2);
+    const bool live = e < TB * in_f && b0 + e / in_f < a.B;
+    const int ec = live ? e : 0;
+    const int bl = ec / in_f, i = ec - bl * in_f, b = b0 + bl;
+    const float xv = x[(size_t)(b < a.B ? b : a.B - 1) * in_f + i];
+    const float xn = tanhf(xv);
+    float dv[4];
+    const Basis4 bs = kan_basis<true>(xn, s_knots, nk, inv_h0, dv);
+    const float* g = s_gz + bl * out_f;
+    float lin = 0.f, spl = 0.f;
+    const int jc = bs.j > 0 ? bs.j : 0;
+    const int j1 = jc >= 1 ? jc - 1 : 0, j2 = jc >= 2 ? jc - 2 : 0, j3 = jc >= 3 ? jc - 3 : 0;
+    const float d0 = bs.j >= 0 ? dv[0] : 0.f, d1 = bs.j >= 1 ? dv[1] : 0.f, d2 = bs.j >= 2 ? dv[2] : 0.f, d3 = bs.j >= 3 ? dv[3] : 0.f;
+#pragma unroll 8
+    for (int o = part; o < out_f; o += 4) {               // branch-free: loads of several outputs in flight
+      const float go = g[o];
+      const float* w = W + ((size_t)i * out_f + o) * nb;
+      const float w0 = w[jc], w1 = w[j1], w2 = w[j2], w3 = w[j3];
+      lin = fmaf(go, lw[(size_t)o * in_f + i], lin);
+      float sv = d0 * w0;
+      sv = fmaf(d1, w1, sv);
+      sv = fmaf(d2, w2, sv);
+      sv = fmaf(d3, w3, sv);
+      spl = fmaf(go, sv, spl);
+    }
+    lin += __shfl_xor(lin, 1); spl += __shfl_xor(spl, 1);
+    lin += __shfl_xor(lin, 2); spl += __shfl_xor(spl, 2);
+    if (live && part == 0) {
+      const float r = fmaf(spl, 1.f - xn * xn, lin);       // d tanh; clamp is the identity on (-1, 1)
+      if (L == 0) a.dx[(size_t)b * in_f + i] = r;
+      else s_gout[bl * KB_MAXW + i] = r;                   // gradient w.r.t. the output of layer L-1
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void kan_stack_bwd_dx_kernel(const KanStackBwdArgs a, int TB) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_knots = smem;                                 // [64]
+  float* s_gz = s_knots + KAN_MAX_KNOTS;                 // [TB][<= 64] dL/dz of the current layer
+  float* s_g0 = s_gz + TB * KB_MAXW;                     // inter-layer gradients, ping-pong
+  float* s_g1 = s_g0 + TB * KB_MAXW;
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int b0 = blockIdx.x * TB;
+  // layer l reads the gradient of its output from buffer (l & 1) and writes the gradient of its input to ((l - 1) & 1)
+  if (a.nl > 3) kb_dx_layer<3>(a, s_knots, s_gz, s_g1, s_g0, b0, TB, tid, T);
+  if (a.nl > 2) kb_dx_layer<2>(a, s_knots, s_gz, s_g0, s_g1, b0, TB, tid, T);
+  if (a.nl > 1) kb_dx_layer<1>(a, s_knots, s_gz, s_g1, s_g0, b0, TB, tid, T);
+  kb_dx_layer<0>(a, s_knots, s_gz, s_g0, s_g1, b0, TB, tid, T);
+}
+
+// parameter gradients of every layer: workgroup -> (layer, input feature i); owns dW[i,:,:], dlin_w[:,i] (and dlin_b for i = 0)
+__global__ __launch_bounds__(1024) void kan_stack_bwd_dw_kernel(const KanStackBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int l = 0;
+#pragma unroll
+  for (int q = 1; q < KB_MAX_LAYERS; ++q)
+    if (q < a.nl && (int)blockIdx.x >= a.wg0[q]) l = q;
+  // (scalar copies of the selected layer: l is workgroup-uniform)
+  int in_f = a.dims[0], out_f = a.dims[1], nk = a.nk[0], BC = a.bc[0], wg0 = a.wg0[0], T = a.thr[0];
+  const float *x = a.x, *knots = a.knots[0], *gzp = a.gz[0];
+  float *dW = a.dW[0], *dlw = a.dlw[0], *dlb = a.dlb[0];
+#pragma unroll
+  for (int q = 1; q < KB_MAX_LAYERS; ++q)
+    if (l == q) {
+      in_f = a.dims[q]; out_f = a.dims[q + 1]; nk = a.nk[q]; BC = a.bc[q]; wg0 = a.wg0[q]; T = a.thr[q];
+      x = a.y[q - 1]; knots = a.knots[q]; gzp = a.gz[q]; dW = a.dW[q]; dlw = a.dlw[q]; dlb = a.dlb[q];
+    }
+  const int B = a.B;
+  float* s_knots = smem;
+  float* s_x = s_knots + KAN_MAX_KNOTS;      // BC
+  float* s_d = s_x + BC;                     // BC * nb dense basis of feature i
+  float* s_gz = s_d + BC * (nk - 4);         // BC * out_f  dL/dz of this batch chunk (read many times below)
+  float* s_part = s_gz + BC * out_f;         // blockDim partial sums
+  // T = the thread count rovit_kan_layer_bwd gives this layer's kan_bwd_dw_kernel (256 or 1024): the same split of the sample
+  // sums, hence bit-identical gradients; threads beyond T only take part in the barriers
+  const int tid = threadIdx.x;
+  const bool on = tid < T;
+  const int nb = nk - 4;
+  const int i = (int)blockIdx.x - wg0;
+  if (tid < nk) s_knots[tid] = knots[tid];
+  __syncthreads();
+  const float inv_h0 = 1.f / (s_knots[1] - s_knots[0]);
+  const int n_sp = out_f * nb;
+  const int n_items = n_sp + out_f + (i == 0 ? out_f : 0);
+  const int nsplit = n_items >= T ? 1 : T / n_items;
+  for (int c0 = 0; c0 < B; c0 += BC) {
+    const int nbatch = min(BC, B - c0);
+    __syncthreads();
+    for (int bl = on ? tid : nbatch; bl < nbatch; bl += T) {
+      const float xv = x[(size_t)(c0 + bl) * in_f + i];
+      const Basis4 bs = kan_basis<false>(tanhf(xv), s_knots, nk, inv_h0, nullptr);
+      float* row = s_d + bl * nb;
+      for (int k = 0; k < nb; ++k) row[k] = 0.f;
+      if (bs.j >= 0) {
+        row[bs.j] = bs.v[0];
+        if (bs.j >= 1) row[bs.j - 1] = bs.v[1];
+        if (bs.j >= 2) row[bs.j - 2] = bs.v[2];
+        if (bs.j >= 3) row[bs.j - 3] = bs.v[3];
+      }
+      s_x[bl] = xv;
+    }
+    {
+      const int n_e = nbatch * out_f;
+      const size_t q0 = (size_t)c0 * out_f;
+      for (int e0 = on ? tid : n_e; e0 < n_e; e0 += T * 8) {
+        float gv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * T;
+          gv[u] = gzp[q0 + (e < n_e ? e : n_e - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * T;
+          if (e < n_e) s_gz[e] = gv[u];
+        }
+      }
+    }
+    __syncthreads();
+    for (int e0 = 0; e0 < n_items; e0 += T) {
+      const int e = e0 + (nsplit == 1 ? tid : tid % n_items);
+      const int part = nsplit == 1 ? 0 : tid / n_items;
+      const bool live = on && e < n_items && part < nsplit;
+      int o = 0, k = 0, kind = 2;             // kind 0: spline weight, 1: linear weight, 2: linear bias
+      if (live) {
+        if (e < n_sp) { kind = 0; k = e / out_f; o = e - k * out_f; }
+        else if (e < n_sp + out_f) { kind = 1; o = e - n_sp; }
+        else { kind = 2; o = e - n_sp - out_f; }
+      }
+      float acc = 0.f;
+      if (live) {
+        const int chunk = (nbatch + nsplit - 1) / nsplit;
+        const int lo = part * chunk, hi = min(nbatch, lo + chunk);
+        const float* mp = kind == 0 ? s_d + k : s_x;          // multiplier stream: stride nb (spline) or 1 (linear)
+        const int ms = kind == 0 ? nb : 1;
+        if (kind == 2) {
+#pragma unroll 8
+          for (int bl = lo; bl < hi; ++bl) acc += s_gz[bl * out_f + o];
+        } else {
+#pragma unroll 8
+          for (int bl = lo; bl < hi; ++bl) acc = fmaf(s_gz[bl * out_f + o], mp[bl * ms], acc);
+        }
+      }
+      if (nsplit > 1) {
+        if (on) s_part[tid] = acc;
+        __syncthreads();
+        if (live && part == 0) {
+          acc = 0.f;
+          for (int p = 0; p < nsplit; ++p) acc += s_part[p * n_items + e];
+        }
+        __syncthreads();
+      }
+      if (live && part == 0) {
+        float* p = kind == 0 ? dW + ((size_t)i * out_f + o) * nb + k : (kind == 1 ? dlw + (size_t)o * in_f + i : dlb + o);
+        *p = c0 == 0 ? acc : *p + acc;
+      }
+    }
+  }
+}
+
 int kan_tb(int out_f) { int tb = 64 / (out_f > 0 ? out_f : 1); return tb < 1 ? 1 : (tb > 16 ? 16 : tb); }
 
 }  // namespace
@@ -559,6 +775,59 @@ extern "C" int rovit_kan_layer_bwd(const float* x, const float* spline_w, const 
     hipLaunchKernelGGL(kan_bwd_dw_kernel, dim3(in_f), dim3(threads), lds, (hipStream_t)stream, x, knots, out, grad_out,
                        d_spline_w, d_lin_w, d_lin_b, batch, in_f, out_f, n_knots, bc, act);
     ROVIT_CHECK_LAUNCH("kan_bwd_dw_kernel");
+  }
+  return ROVIT_OK;
+}
+
+// Backward of the whole stack in two launches (see kan_stack_bwd_dx_kernel).  Host arrays of n_layers device pointers:
+// spline_w (in,out,nb) / knots / lin_w (out,in): the layers' parameters (reference layouts); outs: post-activation outputs of
+// the forward; grad_outs: gradient w.r.t. each layer's output from outside the stack (NULL entries allowed; normally only
+// the last is set); gz: scratch (batch, out_l) per layer; d_spline_w / d_lin_w / d_lin_b: parameter gradients (all set, or
+// d_spline_w == NULL for none); dx: gradient w.r.t. the stack input (batch, dims[0]) or NULL.
+extern "C" int rovit_kan_stack_bwd(const float* x, const float* const* spline_w, const float* const* knots, const float* const* lin_w,
+                                   const float* const* outs, const float* const* grad_outs, float* const* gz, float* dx,
+                                   float* const* d_spline_w, float* const* d_lin_w, float* const* d_lin_b, int batch, const int* dims,
+                                   const int* n_knots, const int* acts, int n_layers, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(x && spline_w && knots && lin_w && outs && grad_outs && gz && dims && n_knots && acts, ROVIT_ERR_NULL, "kan_stack_bwd: null pointer");
+  ROVIT_CHECK_ARG(batch > 0 && n_layers >= 1 && n_layers <= KB_MAX_LAYERS, ROVIT_ERR_SHAPE, "kan_stack_bwd: 1..%d layers", KB_MAX_LAYERS);
+  KanStackBwdArgs a{};
+  a.x = x; a.B = batch; a.nl = n_layers; a.dx = dx;
+  for (int l = 0; l <= n_layers; ++l) a.dims[l] = dims[l];
+  const bool want_dw = d_spline_w != nullptr;
+  size_t lds_dw = 0;
+  int wgs = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    ROVIT_CHECK_ARG(spline_w[l] && knots[l] && lin_w[l] && outs[l] && gz[l], ROVIT_ERR_NULL, "kan_stack_bwd: null pointer in layer %d", l);
+    ROVIT_CHECK_ARG(dims[l] > 0 && dims[l + 1] > 0 && dims[l + 1] <= KB_MAXW, ROVIT_ERR_SHAPE, "kan_stack_bwd: layer %d is %d -> %d; widths after the input must be <= %d",
+                    l, dims[l], dims[l + 1], KB_MAXW);
+    ROVIT_CHECK_ARG(n_knots[l] >= 8 && n_knots[l] <= KAN_MAX_KNOTS, ROVIT_ERR_SHAPE, "kan_stack_bwd: bad knot count %d", n_knots[l]);
+    a.W[l] = spline_w[l]; a.knots[l] = knots[l]; a.lw[l] = lin_w[l]; a.y[l] = outs[l]; a.gy[l] = grad_outs[l]; a.gz[l] = gz[l];
+    a.nk[l] = n_knots[l]; a.act[l] = acts[l];
+    if (want_dw) {
+      ROVIT_CHECK_ARG(d_lin_w && d_lin_b && d_spline_w[l] && d_lin_w[l] && d_lin_b[l], ROVIT_ERR_NULL, "kan_stack_bwd: parameter gradients must be given together");
+      a.dW[l] = d_spline_w[l]; a.dlw[l] = d_lin_w[l]; a.dlb[l] = d_lin_b[l];
+      const int nb = n_knots[l] - 4;
+      int bc = (24 * 1024) / (nb + 1 + dims[l + 1]);
+      bc = bc > batch ? batch : bc;
+      a.bc[l] = bc;
+      a.thr[l] = dims[l + 1] * (nb + 2) >= 512 ? 1024 : 256;
+      const size_t need = (KAN_MAX_KNOTS + (size_t)bc * (nb + 1 + dims[l + 1]) + 1024) * sizeof(float);
+      lds_dw = need > lds_dw ? need : lds_dw;
+    }
+    a.wg0[l] = wgs;
+    wgs += dims[l];
+  }
+  a.wg0[n_layers] = wgs;
+  ROVIT_CHECK_ARG(grad_outs[n_layers - 1] != nullptr, ROVIT_ERR_NULL, "kan_stack_bwd: the gradient of the stack output is missing");
+  // one sample per workgroup up to 1024 samples (every CU gets work at the benchmark's batch sizes), more beyond
+  const int tb = batch <= 1024 ? 1 : (batch <= 4096 ? 4 : 16);
+  const size_t lds_dx = (KAN_MAX_KNOTS + (size_t)3 * tb * KB_MAXW) * sizeof(float);
+  hipLaunchKernelGGL(kan_stack_bwd_dx_kernel, dim3((batch + tb - 1) / tb), dim3(1024), lds_dx, (hipStream_t)stream, a, tb);
+  ROVIT_CHECK_LAUNCH("kan_stack_bwd_dx_kernel");
+  if (want_dw) {
+    ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)kan_stack_bwd_dw_kernel, (size_t)(104 * 1024)), ROVIT_ERR_LAUNCH, "kan_stack_bwd: cannot raise the LDS limit");
+    hipLaunchKernelGGL(kan_stack_bwd_dw_kernel, dim3(wgs), dim3(1024), lds_dw, (hipStream_t)stream, a);
+    ROVIT_CHECK_LAUNCH("kan_stack_bwd_dw_kernel");
   }
   return ROVIT_OK;
 }

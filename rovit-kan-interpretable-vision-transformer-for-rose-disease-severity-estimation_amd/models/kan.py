@@ -131,7 +131,14 @@ class KANSeverityModule(nn.Module):
             prep = self._prepared()
             # from mfma_min_batch samples up the dense form on the matrix cores (rovit_kan_stack_fwd_mfma) is the faster one
             mfma = x.shape[0] >= self.mfma_min_batch and all(p[2] is not None for p in prep)
-            return [x, *KANStackFn.apply(x, codes, prep, mfma, *flat)]
+            return [x, *KANStackFn.apply(x, codes, prep, 2 if mfma else 1, *flat)]
+        if self._fusable():
+            # below that: one forward launch per layer (they split the input features over threads), but still ONE autograd node
+            # whose backward is the two-launch rovit_kan_stack_bwd instead of a dx + dW launch pair per layer
+            flat = []
+            for layer in self.kan_layers:
+                flat += [layer.spline_weights, layer.knots, layer.linear.weight, layer.linear.bias]
+            return [x, *KANStackFn.apply(x, codes, None, 0, *flat)]
         acts = [x]
         for i, layer in enumerate(self.kan_layers):      # activation fused into the layer kernel
             x = layer._run(x, codes[i])

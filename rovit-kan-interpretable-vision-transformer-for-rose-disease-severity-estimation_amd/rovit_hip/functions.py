@@ -55,14 +55,15 @@ class KANLayerFn(torch.autograd.Function):
 
 
 class KANStackFn(torch.autograd.Function):
-    """KANSeverityModule.forward (reference models/kan.py:138-149) as ONE launch (rovit_kan_stack_fwd); backward runs the
-    per-layer kernels in reverse on the activations the fused forward wrote.
-    inputs: x, acts (tuple of ROVIT_ACT_*), prep (list of per-layer (spline_wt, lin_wt, wm) prepared tensors; wm = the
-    matrix-core layout or None), mfma (run rovit_kan_stack_fwd_mfma instead), then per layer (spline_w, knots, lin_w, lin_b);
-    outputs: every layer's output."""
+    """KANSeverityModule.forward (reference models/kan.py:138-149) and its backward as whole-stack launches.
+    forward: mode 0 = one rovit_kan_layer_fwd launch per layer (the faster form below ~2048 samples), 1 = rovit_kan_stack_fwd
+    (one launch, vector ALU), 2 = rovit_kan_stack_fwd_mfma (one launch, matrix cores).  backward (round 3): rovit_kan_stack_bwd,
+    two launches for the whole stack (the per-sample dx chain, then the parameter gradients of every layer).
+    inputs: x, acts (tuple of ROVIT_ACT_*), prep (list of per-layer (spline_wt, lin_wt, wm) prepared tensors or None for mode 0),
+    mode, then per layer (spline_w, knots, lin_w, lin_b); outputs: every layer's output."""
 
     @staticmethod
-    def forward(ctx, x, acts, prep, mfma, *params):
+    def forward(ctx, x, acts, prep, mode, *params):
         import ctypes as C
         x = _f32c(x)
         params = [_f32c(p) for p in params]
@@ -72,44 +73,53 @@ class KANStackFn(torch.autograd.Function):
         nks = [params[4 * l + 1].numel() for l in range(n)]
         outs = [torch.empty(B, dims[l + 1], device=x.device, dtype=torch.float32) for l in range(n)]
         arr = lambda xs: (C.c_int * len(xs))(*xs)
-        if mfma:
+        if mode == 2:
             call('rovit_kan_stack_fwd_mfma', ptr(x), ptr_array([p[2] for p in prep]), ptr_array(params[1::4]), ptr_array(params[3::4]),
                  ptr_array(outs), B, arr(dims), arr(nks), arr(list(acts)), n, stream_ptr())
-        else:
+        elif mode == 1:
             call('rovit_kan_stack_fwd', ptr(x), ptr_array([p[0] for p in prep]), ptr_array(params[1::4]), ptr_array([p[1] for p in prep]),
                  ptr_array(params[3::4]), ptr_array(outs), B, arr(dims), arr(nks), arr(list(acts)), n, stream_ptr())
+        else:
+            st = stream_ptr()
+            for l in range(n):
+                xin = x if l == 0 else outs[l - 1]
+                call('rovit_kan_layer_fwd', ptr(xin), ptr(params[4 * l]), ptr(params[4 * l + 1]), ptr(params[4 * l + 2]), ptr(params[4 * l + 3]),
+                     ptr(outs[l]), B, dims[l], dims[l + 1], nks[l], acts[l], st)
         ctx.save_for_backward(x, *params, *outs)
-        ctx.n, ctx.acts = n, tuple(acts)
+        ctx.n, ctx.acts, ctx.dims, ctx.nks = n, tuple(acts), dims, nks
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gouts):
+        import ctypes as C
         n = ctx.n
         saved = ctx.saved_tensors
         x, params, outs = saved[0], saved[1:1 + 4 * n], saved[1 + 4 * n:]
-        st = stream_ptr()
+        B = x.shape[0]
+        gouts = [(_f32c(g) if g is not None else None) for g in gouts]
+        # layers above the topmost output that received a gradient contribute nothing
+        top = max((l for l in range(n) if gouts[l] is not None), default=-1)
+        if top < 0:
+            return (None,) * (4 + 4 * n)
+        need_dx = ctx.needs_input_grad[0]
+        need_dw = any(ctx.needs_input_grad[4 + 4 * l + k] for l in range(top + 1) for k in (0, 2, 3))
+        nl = top + 1
+        dev = x.device
+        gz = [torch.empty(B, ctx.dims[l + 1], device=dev, dtype=torch.float32) for l in range(nl)]
+        dx = torch.empty_like(x) if need_dx else None
+        dws = [torch.empty_like(params[4 * l]) for l in range(nl)] if need_dw else None
+        dlw = [torch.empty_like(params[4 * l + 2]) for l in range(nl)] if need_dw else None
+        dlb = [torch.empty(ctx.dims[l + 1], device=dev, dtype=torch.float32) for l in range(nl)] if need_dw else None
+        arr = lambda xs: (C.c_int * len(xs))(*xs)
+        call('rovit_kan_stack_bwd', ptr(x), ptr_array(params[0:4 * nl:4]), ptr_array(params[1:4 * nl:4]), ptr_array(params[2:4 * nl:4]),
+             ptr_array(outs[:nl]), ptr_array(gouts[:nl]), ptr_array(gz), ptr(dx),
+             ptr_array(dws) if need_dw else None, ptr_array(dlw) if need_dw else None, ptr_array(dlb) if need_dw else None,
+             B, arr(ctx.dims[:nl + 1]), arr(ctx.nks[:nl]), arr(list(ctx.acts[:nl])), nl, stream_ptr())
         grads = [None] * (4 * n)
-        g = None                                         # dL/d(output of layer l), accumulated from above and from gouts[l]
-        for l in range(n - 1, -1, -1):
-            go = gouts[l]
-            if go is not None:
-                go = _f32c(go)
-                g = go if g is None else g + go
-            if g is None:
-                continue
-            w, knots, lw = params[4 * l], params[4 * l + 1], params[4 * l + 2]
-            xin = x if l == 0 else outs[l - 1]
-            need_dx = l > 0 or ctx.needs_input_grad[0]
-            need_dw = any(ctx.needs_input_grad[4 + 4 * l + k] for k in (0, 2, 3))
-            dx = torch.empty_like(xin) if need_dx else None
-            dws = torch.empty_like(w) if need_dw else None
-            dlw = torch.empty_like(lw) if need_dw else None
-            dlb = torch.empty(lw.shape[0], device=x.device, dtype=torch.float32) if need_dw else None
-            call('rovit_kan_layer_bwd', ptr(xin), ptr(w), ptr(knots), ptr(lw), ptr(outs[l]), ptr(g), ptr(dx), ptr(dws), ptr(dlw),
-                 ptr(dlb), xin.shape[0], xin.shape[1], lw.shape[0], knots.numel(), ctx.acts[l], 0, st)
-            grads[4 * l], grads[4 * l + 2], grads[4 * l + 3] = dws, dlw, dlb
-            g = dx
-        return (g if ctx.needs_input_grad[0] else None, None, None, None, *grads)
+        if need_dw:
+            for l in range(nl):
+                grads[4 * l], grads[4 * l + 2], grads[4 * l + 3] = dws[l], dlw[l], dlb[l]
+        return (dx, None, None, None, *grads)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -30,6 +30,7 @@ SIGNATURES = {
     'rovit_kan_mfma_prepared_floats': (_sz, [_i, _i, _i]),
     'rovit_kan_prepare_mfma': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'rovit_kan_stack_fwd_mfma': (_i, [_vp] * 5 + [_i, _vp, _vp, _vp, _i, _vp]),
+    'rovit_kan_stack_bwd': (_i, [_vp] * 11 + [_i, _vp, _vp, _vp, _i, _vp]),
     'rovit_kan_layer_bwd': (_i, [_vp] * 10 + [_i] * 6 + [_vp]),
     'rovit_linear_fwd': (_i, [_vp] * 5 + [_i] * 4 + [_vp]),
     'rovit_linear_bwd': (_i, [_vp] * 9 + [_i] * 4 + [_vp]),

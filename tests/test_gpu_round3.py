@@ -226,6 +226,70 @@ def test_pipelined_attention_backward_is_bit_identical_to_the_staged_kernel(B, T
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
 
 
+@pytest.mark.parametrize('layers,G,B', [([192, 64, 16, 1], 5, 256), ([192, 64, 16, 1], 32, 512), ([16, 8, 1], 5, 33), ([192, 64, 16, 1], 5, 1),
+                                        ([24, 8, 1], 32, 1500), ([192, 64, 16, 1], 5, 5000), ([10, 1], 5, 7)])
+def test_kan_stack_backward_in_two_launches_is_bit_identical_to_the_per_layer_kernels(layers, G, B):
+    """rovit_kan_stack_bwd (the per-sample dx chain of all layers in one launch + the parameter gradients of all layers in one
+    launch) against rovit_kan_layer_bwd layer by layer: same arithmetic, same summation order, so every gradient is equal bit
+    for bit; and through the module (autograd) against the CPU oracle."""
+    import ctypes as C
+    from models.kan import KANSeverityModule
+    from rovit_hip.functions import ACT_RELU, ACT_SIGMOID3
+    native = _native()
+    p, sp = native.ptr, native.stream_ptr()
+    g = torch.Generator().manual_seed(B + G)
+    sd = ref_cpu.init_kan_state(layers, G, 3, g)
+    m = KANSeverityModule(layers, G, 3)
+    m.load_state_dict(sd)
+    m = m.to(dev())
+    n = len(layers) - 1
+    x = (torch.randn(B, layers[0], generator=g) * 1.5).to(dev())
+    acts = [ACT_RELU] * (n - 1) + [ACT_SIGMOID3]
+    outs = []
+    h = x
+    for i, l in enumerate(m.kan_layers):
+        h = l._run(h, acts[i]).detach()
+        outs.append(h)
+    gout = torch.randn(B, layers[-1], generator=g).to(dev())
+    # per layer
+    ref_dw, gcur, ref_dx = [], gout, None
+    for i in range(n - 1, -1, -1):
+        l = m.kan_layers[i]
+        xin = x if i == 0 else outs[i - 1]
+        dx = torch.empty_like(xin)
+        dws, dlw, dlb = torch.empty_like(l.spline_weights), torch.empty_like(l.linear.weight), torch.empty_like(l.linear.bias)
+        native.call('rovit_kan_layer_bwd', p(xin), p(l.spline_weights), p(l.knots), p(l.linear.weight), p(outs[i]), p(gcur), p(dx), p(dws), p(dlw),
+                    p(dlb), B, l.in_features, l.out_features, l.knots.numel(), acts[i], 0, sp)
+        ref_dw.insert(0, (dws, dlw, dlb))
+        gcur = dx
+    ref_dx = gcur
+    # whole stack
+    arr = lambda xs: (C.c_int * len(xs))(*xs)
+    gz = [torch.empty(B, layers[i + 1], device=dev()) for i in range(n)]
+    dx = torch.full_like(x, float('nan'))
+    dws = [torch.full_like(l.spline_weights, float('nan')) for l in m.kan_layers]
+    dlw = [torch.full_like(l.linear.weight, float('nan')) for l in m.kan_layers]
+    dlb = [torch.full_like(l.linear.bias, float('nan')) for l in m.kan_layers]
+    pa = native.ptr_array
+    native.call('rovit_kan_stack_bwd', p(x), pa([l.spline_weights for l in m.kan_layers]), pa([l.knots for l in m.kan_layers]),
+                pa([l.linear.weight for l in m.kan_layers]), pa(outs), pa([None] * (n - 1) + [gout]), pa(gz), p(dx), pa(dws), pa(dlw), pa(dlb),
+                B, arr(layers), arr([l.knots.numel() for l in m.kan_layers]), arr(acts), n, sp)
+    assert torch.equal(dx, ref_dx)
+    for i in range(n):
+        assert torch.equal(dws[i], ref_dw[i][0]) and torch.equal(dlw[i], ref_dw[i][1]) and torch.equal(dlb[i], ref_dw[i][2]), i
+    # through the module: ONE autograd node for the stack, gradients vs the CPU oracle
+    xd = x.clone().requires_grad_(True)
+    y = m(xd)
+    assert y.grad_fn is not None and 'KANStackFn' in type(y.grad_fn).__name__
+    (y * gout).sum().backward()
+    rp = {k: (v.clone().requires_grad_(True) if 'knots' not in k else v) for k, v in sd.items()}
+    xr = x.cpu().clone().requires_grad_(True)
+    (ref_cpu.kan_module_forward(xr, rp) * gout.cpu()).sum().backward()
+    for k, prm in m.named_parameters():
+        assert float((prm.grad.cpu() - rp[k].grad).abs().max()) < 5e-4 * float(rp[k].grad.abs().max() + 1e-6), k
+    assert float((xd.grad.cpu() - xr.grad).abs().max()) < 5e-4 * float(xr.grad.abs().max() + 1e-9)
+
+
 def test_backbone_forward_with_the_fused_mlp_half_matches_the_two_launch_build_of_the_same_forward():
     """ROVIT_MLP_FUSED=0 (read once per process) selects the two-launch MLP half: run both in subprocesses on the same seeded
     weights and images, training workspaces, and compare features, every gradient and the saved act / gelu' of a block."""

@@ -66,6 +66,7 @@ class KANStackFn(torch.autograd.Function):
     def forward(ctx, x, acts, prep, mode, *params):
         import ctypes as C
         x = _f32c(x)
+        ptr(x)                                     # a CPU tensor is refused here (RovitHipError), before anything asks for a stream
         params = [_f32c(p) for p in params]
         n = len(params) // 4
         B = x.shape[0]

@@ -198,11 +198,14 @@ int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const float* b1,
  * wstream_bwd: rovit_mlp_prepare_stream(w1f := W2T bf16 (768,192), w2 := W1T bf16 (192,768), norm2 affine folded in). */
 int rovit_mlp_fused_bwd(const void* dY, const void* wstream_bwd, const void* dact, void* dpre, const void* xhat2, const float* rstd2,
                         float* dX, void* dXb, int M, rovit_stream_t stream);
+/* developer knob (timing ablations of the lockstep fused MLP kernels: bit 0 skip the row-wise epilogue, 1 skip GELU, 2 skip fc2, 3 skip fc1; results are then wrong) */
+int rovit_set_mlp_debug(int bits);
 /* developer knob (timing ablations of rovit_attention_bwd: bit 0 skip pass 1, bit 1 skip pass 2; results are then wrong) */
 int rovit_set_attn_debug(int bits);
 /* developer knob: rovit_attention_bwd as persistent workgroups with LDS-DMA prefetch (1) or the staged kernel (0, default: faster); bit-identical results */
 int rovit_set_attn_bwd_pipe(int on);
-/* developer knob (A/B timing): waves per workgroup of rovit_mlp_fused_fwd, 8 = one 256-row workgroup per CU, 4 = two 128-row ones */
+/* developer knob (A/B timing): waves per workgroup of rovit_mlp_fused_fwd, 8 = one 256-row workgroup per CU (default), 4 = two 128-row
+ * ones, 9 = 8 waves with waves 4-7 staggered half a chunk behind waves 0-3 */
 int rovit_set_mlp_waves(int waves);
 /* dgrad through a Linear that follows a LayerNorm, fused with that LayerNorm's backward:
  * dxhat = dY W^T;  dX += rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat));  dXb = bf16(dX) */

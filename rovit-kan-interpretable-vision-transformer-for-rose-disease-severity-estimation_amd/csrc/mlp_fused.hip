@@ -71,6 +71,7 @@ struct MlpArgs {
   bf16* xb;               // backward: (M,192) bf16 copy of the updated dX
   float eps;
   int M;
+  int dbg;                // developer knob (timing ablations of the lockstep kernel): bit 0 skip the row-wise epilogue, 1 skip GELU, 2 skip fc2, 3 skip fc1
 };
 
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
@@ -79,8 +80,20 @@ template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // KIND 0 forward (MODE 0: inference, nothing kept; 1: keep act; 2: keep act and gelu'), KIND 1 backward (MODE 1: dpre kept)
-template <int KIND, int MODE, int NW>
+// STAG (forward, 8 waves): waves 4-7 run HALF A CHUNK behind waves 0-3 in program order (MI355X guide, "two waves per SIMD",
+// item 9).  The two waves of a SIMD otherwise move in lockstep through [fc1: matrix pipe] [GELU: vector pipe] [fc2: matrix pipe]:
+// they contend for the matrix pipe, then both sit in the ~300-instruction GELU that a single wave issues at half the vector
+// rate, and nothing overlaps (measured: 3400 cycles per chunk for 1536 cycles of matrix time).  Staggered,
+//   waves 0-3:  fc1(c)          | GELU tile 0, tile 1 (c)         | fc2(c)
+//   waves 4-7:  GELU tile 1 (c-1) | fc2(c-1) | fc1(c)              | GELU tile 0 (c)
+// one wave's matrix segments fall into its partner's GELU.  Waves 4-7 carry the tile-1 pre-activations and the tile-0 GELU
+// output of chunk c-1 across the barrier (12 registers), read chunk c-1's fc2 fragments one iteration later (so the ring has
+// FOUR slots: 96 KB, still under the staged output tile it aliases), issue out-of-range (dropped, but counted) stores in
+// their first iteration so that the vmcnt arithmetic is the same for every wave, and finish chunk 23 behind the loop.
+// Outputs are bit-identical to the unstaggered kernel (same operations on the same values, per wave in the same order).
+template <int KIND, int MODE, int NW, bool STAG = false>
 __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) {
+  static_assert(!STAG || (KIND == 0 && NW == 8), "the staggered schedule is the 8-wave forward's");
   constexpr int S = 2 * MODE;                 // stores one wave issues per chunk
   constexpr int ROWS = 32 * NW;               // rows per workgroup: wave w owns the 16-row tiles w and w + NW
   constexpr int PW = CH_PIECES / NW + (KIND ? 2 : 0);   // DMA pieces one wave issues per chunk
@@ -141,6 +154,132 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
     for (int i = 0; i < 2; ++i) a2[ot][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // bias ds_writes retired before the first barrier
+  if constexpr (STAG) {
+    static_assert(4 * CH_ELEMS <= region_elems(0, 8), "four ring slots must fit under the staged output tile");
+    const bool late = w >= NW / 2;                            // wave-uniform
+    // The xhat2 fragments of tile 1 live in LDS (48 KB behind the biases: this wave's own 6 KB, lane-linear, written once): with
+    // both tiles' fragments in registers the staggered loop needs ~265 registers and the allocator spills two fragments, whose
+    // reloads inside the loop are vector-memory operations that drain the ring
+    bf16* xl = lds + region_elems(0, NW) + 2 * (HID + D) + w * 6 * PIECE + lane * 8;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) *(bf16x8*)(xl + ks * PIECE) = xf[1][ks];
+    auto fc1 = [&](const bf16* sb, int c, f32x4 (&a1)[2][2]) {
+      const f32x4 ba = *(const f32x4*)(s_bias + c * HC + 8 * lg), bb = *(const f32x4*)(s_bias + c * HC + 8 * lg + 4);
+      a1[0][0] = ba; a1[0][1] = ba; a1[1][0] = bb; a1[1][1] = bb;
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) {
+        const bf16x8 wa = *(const bf16x8*)(sb + ks * PIECE), wb = *(const bf16x8*)(sb + (6 + ks) * PIECE);
+        const bf16x8 x1 = *(const bf16x8*)(xl + ks * PIECE);
+        if (g.dbg & 8) continue;
+        a1[0][0] = mfma16(wa, xf[0][ks], a1[0][0]);
+        a1[1][0] = mfma16(wb, xf[0][ks], a1[1][0]);
+        a1[0][1] = mfma16(wa, x1, a1[0][1]);
+        a1[1][1] = mfma16(wb, x1, a1[1][1]);
+      }
+    };
+    auto gelu_tile = [&](const f32x4& pa, const f32x4& pb, bf16x8& av, bf16x8& dv) {      // tile a / tile b rows of ONE 16-row tile
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float ga, gd;
+        if (g.dbg & 2) { av[r] = (bf16)pa[r]; dv[r] = av[r]; av[4 + r] = (bf16)pb[r]; dv[4 + r] = av[4 + r]; continue; }
+        gelu_and_grad((float)(bf16)pa[r], ga, gd);
+        av[r] = (bf16)ga; dv[r] = (bf16)gd;
+        gelu_and_grad((float)(bf16)pb[r], ga, gd);
+        av[4 + r] = (bf16)ga; dv[4 + r] = (bf16)gd;
+      }
+    };
+    auto store_tile = [&](int i, int c, const bf16x8& av, const bf16x8& dv) {
+      if (MODE >= 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, av), r_act, soff[i] + c * (HC * 2), 0, 0);
+      if (MODE == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dv), r_dact, soff[i] + c * (HC * 2), 0, 0);
+    };
+    auto fc2 = [&](const bf16* sb, const bf16x8& av0, const bf16x8& av1) {
+#pragma unroll
+      for (int ot = 0; ot < 12; ++ot) {
+        const bf16x8 w2 = *(const bf16x8*)(sb + (12 + ot) * PIECE);
+        if (g.dbg & 4) continue;
+        a2[ot][0] = mfma16(w2, av0, a2[ot][0]);
+        a2[ot][1] = mfma16(w2, av1, a2[ot][1]);
+      }
+    };
+    // Half-steps of a chunk c:  H2(c) = fc1 of chunk c (matrix pipe), GELU of its tile 0 (vector pipe), stores of tile 0;
+    //                           H1(c+1) = GELU of tile 1 of chunk c, its stores, fc2 of chunk c (both tiles).
+    // Waves 0-3 run H2(c) | H1(c+1) in iteration c (the lockstep order with a barrier in the middle), waves 4-7 run H1(c) | H2(c):
+    // in every half-iteration one wave of a SIMD is in [matrix, vector] order and its partner in [vector, matrix] order.  The two
+    // groups have their own straight-line loops (one loop with a role branch inside made hipcc shuttle the 96 accumulator
+    // registers through ~150 v_mov_b64 per half-step).  Chunk c is read from the top of iteration c until the first half of
+    // iteration c + 1 (waves 4-7's fc2), its DMA is issued at the top of iteration c - 2 into ring slot c % 4, whose previous
+    // tenant, chunk c - 4, was last read in iteration c - 3.
+    bf16x8 keep_pre = {};            // bf16(pre-activation) of tile 1: elements 0-3 tile a rows, 4-7 tile b rows
+    bf16x8 keep_av0 = {};
+    auto top = [&](int c) {
+      if (c == 0) wait_vm<PW>();
+      else if (c == 1) wait_vm<PW + S>();
+      else if (c < NCHUNK - 1) wait_vm<PW + 2 * S>();
+      else wait_vm<2 * S>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (c + 2 < NCHUNK) dma(c + 2, (c + 2) & 3);
+    };
+    auto mid = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+    auto H2 = [&](int c) {
+      const bf16* sb = lds + (c & 3) * SLOT + lane * 8;
+      f32x4 a1[2][2];
+      fc1(sb, c, a1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { keep_pre[r] = (bf16)a1[0][1][r]; keep_pre[4 + r] = (bf16)a1[1][1][r]; }
+      asm volatile("" : "+v"(keep_pre));                    // packed NOW: the eight fp32 registers of tile 1 are free during the GELU
+      bf16x8 dv0;
+      gelu_tile(a1[0][0], a1[1][0], keep_av0, dv0);
+      store_tile(0, c, keep_av0, dv0);
+    };
+    auto H1 = [&](int c) {                                   // second half of chunk c - 1
+      bf16x8 av1, dv1;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float ga, gd;
+        gelu_and_grad((float)keep_pre[r], ga, gd);
+        av1[r] = (bf16)ga; dv1[r] = (bf16)gd;
+      }
+      store_tile(1, c - 1, av1, dv1);
+      fc2(lds + ((c - 1) & 3) * SLOT + lane * 8, keep_av0, av1);
+    };
+    if (!late) {
+#pragma unroll 1
+      for (int c = 0; c < NCHUNK; ++c) {
+        top(c);
+        H2(c);
+        mid();
+        H1(c + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      mid();                                                 // pairs with the barrier in front of the other group's last half-step
+    } else {
+      top(0);
+      {                                                      // nothing to finish yet: the same store count, out of range (dropped, but counted)
+        const u32x4v z = {0u, 0u, 0u, 0u};
+        if (MODE >= 1) __builtin_amdgcn_raw_buffer_store_b128(z, r_act, 0xFFFFFF00u, 0, 0);
+        if (MODE == 2) __builtin_amdgcn_raw_buffer_store_b128(z, r_dact, 0xFFFFFF00u, 0, 0);
+      }
+      mid();
+      H2(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+      for (int c = 1; c < NCHUNK; ++c) {
+        top(c);
+        H1(c);
+        mid();
+        H2(c);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      mid();
+      H1(NCHUNK);                                            // chunk 23's second half
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  } else {
   int slot = 0;
 #pragma unroll 1
   for (int c = 0; c < NCHUNK; ++c) {
@@ -163,6 +302,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
     } else {
       a1[0][0] = a1[0][1] = a1[1][0] = a1[1][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    if (!(g.dbg & 8))
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) {
       const bf16x8 wa = *(const bf16x8*)(sb + ks * PIECE), wb = *(const bf16x8*)(sb + (6 + ks) * PIECE);
@@ -182,7 +322,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float ga, gd;
-            gelu_and_grad((float)(bf16)a1[t][i][r], ga, gd);      // the two-launch path's GELU sees the bf16-staged pre-activation
+            if (g.dbg & 2) { ga = a1[t][i][r]; gd = ga; }
+            else gelu_and_grad((float)(bf16)a1[t][i][r], ga, gd);      // the two-launch path's GELU sees the bf16-staged pre-activation
             av[i][4 * t + r] = (bf16)ga;
             dv[i][4 * t + r] = (bf16)gd;
           }
@@ -205,6 +346,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
       }
     }
     // ---- second GEMM: out^T[192][32 rows] += W[:, chunk] act^T ----
+    if (!(g.dbg & 4))
 #pragma unroll
     for (int ot = 0; ot < 12; ++ot) {
       const bf16x8 w2 = *(const bf16x8*)(sb + (12 + ot) * PIECE);
@@ -215,9 +357,15 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
     slot = slot == 2 ? 0 : slot + 1;
   }
 
+  }
+
   // ---- epilogue: bf16(out [+ b2]) staged in LDS (aliases the ring: every wave must have left the loop) ----
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  if (g.dbg & 1) {                                          // timing ablation: no epilogue (keep the accumulators alive)
+    if (a2[0][0][0] == 12345.678f && a2[11][1][3] == 1.f) g.X[0] = a2[5][0][1];
+    return;
+  }
   // Row-wise pass, 16 lanes per row (lane c16 holds elements {64 i + 4 c16 .. +3}), 8 passes of RP = 4 NW rows.  The residual rows of
   // passes 0-3 are requested BEFORE the staging writes and those of passes 4-7 before passes 0-3 are processed, so that the
   // pass is not a chain of eight dependent HBM round trips (the accumulators' 96 registers are free by then).
@@ -368,11 +516,22 @@ __global__ __launch_bounds__(256) void mlp_stream_prep_kernel(const MlpPrepArgs 
 // workgroups per CU); environment ROVIT_MLP_WAVES
 // (measured on MI355X, batch 256, training step: 8 waves 5.86 ms, 4 waves 5.97 ms, two-launch MLP half 5.96 ms)
 static int g_mlp_waves = [] { const char* e = getenv("ROVIT_MLP_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+// waves 4-7 half a chunk behind waves 0-3 (see the kernel): OPT-IN (ROVIT_MLP_STAGGER=1 / rovit_set_mlp_waves(9)).  Measured with the
+// ablation knobs (tools/mlp_ablate.py, profiles/r03_mlp_ablation.json): in lockstep the launch is the SUM of its parts --
+// ring + barriers 14 us, matrix pipe 20 us, GELU 22 us, row-wise epilogue 16 us (inference variant, 71 us on that box) --
+// and the stagger does hide the GELU behind the partner's matrix segments (22 -> 10 us exposed), but the two extra barriers per
+// chunk and the LDS-resident fragments give 5 us back: 68 against 71 us on one box, 76 against 75 on another.  Not a robust
+// win, so the simpler lockstep kernel stays the default.
+static int g_mlp_stagger = [] { const char* e = getenv("ROVIT_MLP_STAGGER"); return (e && e[0] == '1') ? 1 : 0; }();
 extern "C" int rovit_set_mlp_waves(int nw) {
-  ROVIT_CHECK_ARG(nw == 4 || nw == 8, ROVIT_ERR_SHAPE, "set_mlp_waves: 4 or 8 (got %d)", nw);
-  g_mlp_waves = nw;
+  ROVIT_CHECK_ARG(nw == 4 || nw == 8 || nw == 9, ROVIT_ERR_SHAPE, "set_mlp_waves: 4, 8 or 9 (= 8 waves, staggered) (got %d)", nw);
+  g_mlp_stagger = nw == 9;
+  g_mlp_waves = nw == 9 ? 8 : nw;
   return ROVIT_OK;
 }
+
+static int g_mlp_dbg = 0;
+extern "C" int rovit_set_mlp_debug(int bits) { g_mlp_dbg = bits; return ROVIT_OK; }
 
 extern "C" size_t rovit_mlp_stream_bytes(void) { return (size_t)NCHUNK * CH_ELEMS * sizeof(bf16); }
 
@@ -410,7 +569,7 @@ extern "C" int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const
                   ROVIT_ERR_ALIGN, "mlp_fused_fwd: buffers must be 16-byte aligned");
   MlpArgs g{};
   g.xin = (const bf16*)xhat2; g.wstream = (const bf16*)wstream; g.b1 = b1; g.b2 = b2; g.act = (bf16*)act; g.dact = (bf16*)dact;
-  g.X = X; g.xhat = (bf16*)xhat_out; g.rstd = rstd_out; g.eps = eps; g.M = M;
+  g.X = X; g.xhat = (bf16*)xhat_out; g.rstd = rstd_out; g.eps = eps; g.M = M; g.dbg = g_mlp_dbg;
   hipStream_t st = (hipStream_t)stream;
   const int nw = g_mlp_waves;
   const dim3 grid((M + 32 * nw - 1) / (32 * nw)), block(64 * nw);
@@ -420,7 +579,16 @@ extern "C" int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const
                     "mlp_fused_fwd: cannot raise the LDS limit");                                                                \
     hipLaunchKernelGGL((mlp_fused_kernel<0, MD, NWV>), grid, block, lds_bytes(0, NWV), st, g);                                   \
   } while (0)
-  if (nw == 8) {
+  if (nw == 8 && g_mlp_stagger) {
+#define LAUNCH_STAG(MD)                                                                                                          \
+  do {                                                                                                                           \
+    ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<0, MD, 8, true>, lds_bytes(0, 8) + 8 * 6 * 1024), ROVIT_ERR_LAUNCH, \
+                    "mlp_fused_fwd: cannot raise the LDS limit");                                                                \
+    hipLaunchKernelGGL((mlp_fused_kernel<0, MD, 8, true>), grid, block, lds_bytes(0, 8) + 8 * 6 * 1024, st, g);                  \
+  } while (0)
+    if (!act) LAUNCH_STAG(0); else if (!dact) LAUNCH_STAG(1); else LAUNCH_STAG(2);
+#undef LAUNCH_STAG
+  } else if (nw == 8) {
     if (!act) LAUNCH_MODE(0, 8); else if (!dact) LAUNCH_MODE(1, 8); else LAUNCH_MODE(2, 8);
   } else {
     if (!act) LAUNCH_MODE(0, 4); else if (!dact) LAUNCH_MODE(1, 4); else LAUNCH_MODE(2, 4);
@@ -442,7 +610,7 @@ extern "C" int rovit_mlp_fused_bwd(const void* dY, const void* wstream_bwd, cons
                   ROVIT_ERR_ALIGN, "mlp_fused_bwd: buffers must be 16-byte aligned");
   MlpArgs g{};
   g.xin = (const bf16*)dY; g.wstream = (const bf16*)wstream_bwd; g.act = (bf16*)dpre; g.mul = (const bf16*)dact; g.X = dX;
-  g.xhat = (bf16*)const_cast<void*>(xhat2); g.rstd = const_cast<float*>(rstd2); g.xb = (bf16*)dXb; g.M = M;
+  g.xhat = (bf16*)const_cast<void*>(xhat2); g.rstd = const_cast<float*>(rstd2); g.xb = (bf16*)dXb; g.M = M; g.dbg = g_mlp_dbg;
   ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<1, 1, 8>, lds_bytes(1, 8)), ROVIT_ERR_LAUNCH,
                   "mlp_fused_bwd: cannot raise the LDS limit");
   hipLaunchKernelGGL((mlp_fused_kernel<1, 1, 8>), dim3((M + 255) / 256), dim3(512), lds_bytes(1, 8), (hipStream_t)stream, g);

@@ -56,6 +56,7 @@ SIGNATURES = {
     'rovit_mlp_fused_fwd': (_i, [_vp] * 9 + [_f, _i, _vp]),
     'rovit_mlp_fused_bwd': (_i, [_vp] * 8 + [_i, _vp]),
     'rovit_set_mlp_waves': (_i, [_i]),
+    'rovit_set_mlp_debug': (_i, [_i]),
     'rovit_set_attn_debug': (_i, [_i]),
     'rovit_set_attn_bwd_pipe': (_i, [_i]),
     'rovit_gemm_ln_bwd': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -66,7 +66,7 @@ def _fused(native, xhat2, w1, w2, b1, b2, X0, mode=2, ln=True, waves=None):
     return act, dact, X, xhat, rstd
 
 
-@pytest.mark.parametrize('waves', [4, 8])
+@pytest.mark.parametrize('waves', [4, 8, 9])       # 8 = lockstep (default), 9 = the same 8 waves with waves 4-7 staggered by half a chunk
 @pytest.mark.parametrize('M', [1, 5, 129, 197, 256, 257, 591, 1000, 3 * 197 * 4, 256 * 197])
 def test_fused_mlp_half_equals_the_two_launch_path_and_a_torch_reference(M, waves):
     """rovit_mlp_fused_fwd = rovit_gemm_nt(EPI_GELU) + rovit_gemm_resid_ln in one launch.  act and gelu' must be BIT-IDENTICAL to the

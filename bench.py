@@ -205,14 +205,14 @@ def mlp_roofline(dev):
 
 
 def wgrad_roofline(dev, iters=30):
-    """Dominant kernel of the step (rocprofv3 summaries in profiles/): wgrad_kernel<64,192,false>, the ONE weight-gradient
-    launch per transformer block: G = dY^T A for the qkv, fc2, fc1 and proj linears together (M = 50432 rows, 36 output
-    tiles of 64 x 192 per M-split, 14 splits = 504 workgroups).  Timed from device events on the stream it is launched on.  HBM-bound
+    """Dominant kernel of the step (rocprofv3 summaries in profiles/): wgrad_kernel<192,192,..,4>, the ONE weight-gradient
+    launch per transformer block: G = dY^T A for the qkv, fc2, fc1 and proj linears together (M = 50432 rows, 12 output
+    tiles of 192 x 192 per M-split, eight waves per workgroup, 16 splits = 192 workgroups: the step's configuration).  Timed from device events on the stream it is launched on.  HBM-bound
     (<= 48 FLOP per byte read): achieved = algorithmic bytes / duration against the HBM peak."""
     import ctypes as C
     from rovit_hip import native
     lib = native.load()
-    M, splits = 256 * 197, 14
+    M, splits = 256 * 197, 16
     shapes = [(576, 192), (192, 768), (768, 192), (192, 192)]       # (N, K) of qkv, fc2, fc1, proj
     dY = [torch.randn(M, n, device=dev).to(torch.bfloat16) for n, _ in shapes]
     A = [torch.randn(M, k, device=dev).to(torch.bfloat16) for _, k in shapes]
@@ -228,13 +228,13 @@ def wgrad_roofline(dev, iters=30):
     ms_train = _event_avg_ms(dev, run, iters, per_launch=False)
     flops = sum(2.0 * M * n * k for n, k in shapes)
     # algorithmic bytes per launch: read dY (M*N) and A (M*K) in bf16 once, write one fp32 G (N*K), per
-    # problem (the 16 partial slabs the kernel really writes count as traffic, not as algorithmic bytes)
+    # problem (the partial slabs the kernel really writes count as traffic, not as algorithmic bytes)
     alg_bytes = sum(2.0 * M * (n + k) + 4.0 * n * k for n, k in shapes)
     gbs = alg_bytes / (ms * 1e-3) / 1e9
-    return {'bound': 'hbm', 'kernel': f'wgrad_kernel<64,192,false>: weight gradients of one block (qkv+fc2+fc1+proj) in one launch, M=50432, {splits} M-splits',
+    return {'bound': 'hbm', 'kernel': f'wgrad_kernel<192,192,false,false,4>: weight gradients of one block (qkv+fc2+fc1+proj) in one launch, M=50432, {splits} M-splits',
             'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
             'avg_us': round(ms * 1e3, 2), 'avg_us_back_to_back': round(ms_train * 1e3, 2), 'algorithmic_bytes': alg_bytes,
-            'traffic': _pmc_traffic('wgrad_kernel<64,192,false>'),
+            'traffic': _pmc_traffic('wgrad_kernel<192,192>'),
             'mfma_tflops': round(flops / (ms * 1e-3) / 1e12, 1)}
 
 

@@ -1199,13 +1199,15 @@ struct WgradArgs {
 // wave tile TK/2 x TN/2.  Smaller tiles mean fewer M-splits for the same number of workgroups, i.e. fewer fp32 partial
 // slabs to write and reduce (slab bytes = splits x N x K x 4), at the price of more operand re-reads through the XCD's
 // L2 (every tile of a split streams the same rows; all tiles of a split run on one XCD).
-template <int TN, int TK, bool PATCH, bool IMG = false>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
+// WN = waves along n (2: the four-wave workgroup above; 4: EIGHT waves as 2 (k) x 4 (n) for 192 x 192 tiles, round 3).
+template <int TN, int TK, bool PATCH, bool IMG = false, int WN = 2>
+__global__ __launch_bounds__(128 * WN) void wgrad_kernel(const WgradArgs g) {
+  constexpr int NT = 128 * WN;
   constexpr int SY = wg_stride(TN), SA = wg_stride(TK);
   constexpr int CPRY = TN / 8, CPRA = TK / 8;           // 16-byte chunks per tile row
-  constexpr int CHY = WG_MSTEP * CPRY / 256, CHA = WG_MSTEP * CPRA / 256;   // chunks per thread and step
-  constexpr int JN = TN / 32, IK = TK / 32;             // 16 x 16 accumulator tiles per wave: IK (k) x JN (n)
-  static_assert(TN % 32 == 0 && TK % 32 == 0, "wave tiles are multiples of 16");
+  constexpr int CHY = WG_MSTEP * CPRY / NT, CHA = WG_MSTEP * CPRA / NT;   // chunks per thread and step
+  constexpr int JN = TN / (16 * WN), IK = TK / 32;      // 16 x 16 accumulator tiles per wave: IK (k) x JN (n)
+  static_assert(TN % (16 * WN) == 0 && TK % 32 == 0 && (WG_MSTEP * CPRY) % NT == 0 && (WG_MSTEP * CPRA) % NT == 0, "tile must split evenly over the waves");
   __shared__ __attribute__((aligned(16))) bf16 lds[2 * WG_MSTEP * (SY + SA)];
   bf16* Ys = lds;                                       // [2][MSTEP][SY]
   bf16* As = lds + 2 * WG_MSTEP * SY;                   // [2][MSTEP][SA]
@@ -1227,7 +1229,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   const int m_end = min(g.M, m_begin + g.rows_per_split);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wk = wave >> 1, wn = wave & 1;              // wave tile: k rows [TK/2*wk, +TK/2), n cols [TN/2*wn, +TN/2)
+  const int wk = wave / WN, wn = wave % WN;             // wave tile: k rows [TK/2*wk, +TK/2), n cols [TN/WN*wn, +TN/WN)
   const int l15 = lane & 15, lg = lane >> 4;
 
   // Per-thread staging chunks.  Keep the hot loop free of address arithmetic: one clamped row index and one
@@ -1238,7 +1240,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   using RA = typename std::conditional<IMG, F8, bf16x8>::type;      // IMG: raw pixels wait in registers, packed at the LDS store
 #pragma unroll
   for (int i = 0; i < CHY; ++i) {
-    const int c = tid + i * 256;
+    const int c = tid + i * NT;
     y_row[i] = c / CPRY;
     const int col = (c - y_row[i] * CPRY) * 8;
     y_lds[i] = y_row[i] * SY + col;
@@ -1246,7 +1248,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   }
 #pragma unroll
   for (int i = 0; i < CHA; ++i) {
-    const int c = tid + i * 256;
+    const int c = tid + i * NT;
     int col;
     if (IMG) {      // 32 neighbouring patches x both halves of a 16-pixel segment per wave (see gemm_ws_kernel)
       const int rest = c >> 6, row_hi = rest / (CPRA / 2), pair = rest - row_hi * (CPRA / 2);
@@ -1316,7 +1318,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
 
   const int nsteps = (m_end - m_begin + WG_MSTEP - 1) / WG_MSTEP;
   // transposed-read lane address inside a [rows][stride] tile: row 4*lg + (l15>>2), col 4*(l15&3)
-  const bf16* Ybase = Ys + (4 * lg + (l15 >> 2)) * SY + 4 * (l15 & 3) + wn * (TN / 2);
+  const bf16* Ybase = Ys + (4 * lg + (l15 >> 2)) * SY + 4 * (l15 & 3) + wn * (TN / WN);
   const bf16* Abase = As + (4 * lg + (l15 >> 2)) * SA + 4 * (l15 & 3) + wk * (TK / 2);
   auto compute = [&](int cur) {
     const bf16* Yc = Ybase + cur * WG_MSTEP * SY;
@@ -1368,7 +1370,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   float* slab = pr.slab + (size_t)split * pr.N * pr.K;
 #pragma unroll
   for (int j = 0; j < JN; ++j) {
-    const int n = n0 + wn * (TN / 2) + j * 16 + l15;
+    const int n = n0 + wn * (TN / WN) + j * 16 + l15;
 #pragma unroll
     for (int i = 0; i < IK; ++i) {
       const int k = k0 + wk * (TK / 2) + i * 16 + lg * 4;
@@ -1571,7 +1573,7 @@ extern "C" int rovit_wgrad_splits(int M, int N, int K) {
   return s < 1 ? 1 : s;
 }
 
-template <int TN, int TK>
+template <int TN, int TK, int WN = 2>
 static void launch_wgrad(const WgradArgs& g0, hipStream_t st) {
   WgradArgs g = g0;
   int t = 0;
@@ -1582,9 +1584,13 @@ static void launch_wgrad(const WgradArgs& g0, hipStream_t st) {
   }
   g.tiles_per_split = t;
   const int nwg = g.splits * t;
-  if (g.patch_tokens > 0 && g.img) hipLaunchKernelGGL((wgrad_kernel<TN, TK, true, true>), dim3(nwg), dim3(256), 0, st, g);
-  else if (g.patch_tokens > 0) hipLaunchKernelGGL((wgrad_kernel<TN, TK, true>), dim3(nwg), dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((wgrad_kernel<TN, TK, false>), dim3(nwg), dim3(256), 0, st, g);
+  if constexpr (WN != 2) {
+    hipLaunchKernelGGL((wgrad_kernel<TN, TK, false, false, WN>), dim3(nwg), dim3(128 * WN), 0, st, g);
+  } else {
+    if (g.patch_tokens > 0 && g.img) hipLaunchKernelGGL((wgrad_kernel<TN, TK, true, true>), dim3(nwg), dim3(256), 0, st, g);
+    else if (g.patch_tokens > 0) hipLaunchKernelGGL((wgrad_kernel<TN, TK, true>), dim3(nwg), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((wgrad_kernel<TN, TK, false>), dim3(nwg), dim3(256), 0, st, g);
+  }
 }
 
 // slab/colsum live in `ws` (rovit_wgrad_workspace_bytes); results are produced by rovit_wgrad_reduce.
@@ -1664,12 +1670,17 @@ int rovit_wgrad_batch(const RovitWgradDesc* descs, int n, int M, int splits, rov
   // a lone problem (the qkv weight gradient flushed at the end of a data-parallel block range): 96 x 96 tiles give twice the
   // workgroups for the same 16 M-splits (96 -> 192); every element still sums the same rows in the same order, so the
   // result is bit-identical to the merged launch's
-  // 64 x 192 tiles (round 3): 36 tiles per M-split instead of 24, so 14 splits make 504 workgroups = two per CU on 252 CUs, where
-  // 16 x 24 = 384 left half of the CUs with one workgroup and half with two (the launch then lasts as long as the doubly loaded
-  // half), and two slabs fewer are written.  Step 5.61-5.66 -> 5.54-5.62 ms on the same box.  ROVIT_WGRAD_MERGE_TN=96: round 2's tiles.
-  static const int merge_tn = getenv("ROVIT_WGRAD_MERGE_TN") ? atoi(getenv("ROVIT_WGRAD_MERGE_TN")) : 64;
+  // 192 x 192 tiles with eight waves (round 3, the default): every row of dY and A that a workgroup stages feeds 192 output
+  // columns instead of 64-96, so the L2 -> CU re-read traffic of the launch halves (the per-CU load path, not HBM, bounded the
+  // smaller tiles: DESIGN.md "weight gradients").  12 tiles per M-split; 16 splits = 192 workgroups in the step (the other
+  // stream's dgrad kernels keep the remaining CUs busy), 21 = 252 is the fastest standalone (73 us against 107 us for 64 x 192
+  // tiles x 14 splits on the same box).  ROVIT_WGRAD_MERGE_TN=64 / 96: the earlier four-wave tiles.
+  static const int merge_tn = getenv("ROVIT_WGRAD_MERGE_TN") ? atoi(getenv("ROVIT_WGRAD_MERGE_TN")) : 192;
   if (n == 1 && g.p[0].K % 96 == 0) launch_wgrad<96, 96>(g, (hipStream_t)stream);
-  else if (merge_tn == 64) {
+  else if (merge_tn == 192) {        // 192 x 192 tiles, eight waves: 12 tiles per split
+    for (int j = 0; j < n; ++j) ROVIT_CHECK_ARG(descs[j].N % 192 == 0, ROVIT_ERR_SHAPE, "wgrad_batch: N %% 192 for 192-wide tiles");
+    launch_wgrad<192, 192, 4>(g, (hipStream_t)stream);
+  } else if (merge_tn == 64) {
     for (int j = 0; j < n; ++j) ROVIT_CHECK_ARG(descs[j].N % 64 == 0, ROVIT_ERR_SHAPE, "wgrad_batch: N %% 64 for 64-wide tiles");
     launch_wgrad<64, 192>(g, (hipStream_t)stream);
   } else launch_wgrad<96, 192>(g, (hipStream_t)stream);

@@ -447,9 +447,9 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
     return rovit_wgrad_reduce_batch(rd, 4, st);
   };
   // Weight gradients of the two-stream schedule: ONE launch per block carries the qkv gradient of the previous block
-  // (`pending`, whose dqkv became final with its A5) together with fc2 / fc1 / proj of block i -- 24 output tiles per
+  // (`pending`, whose dqkv became final with its A5) together with fc2 / fc1 / proj of block i -- 12 output tiles (192 x 192) per
   // M-split, so S_MERGE splits fill the chip (see gemm.hip WgradProb) -- and ONE reduce launch finishes those four.
-  static const int s_merge_env = getenv("ROVIT_WGRAD_MERGE_SPLITS") ? atoi(getenv("ROVIT_WGRAD_MERGE_SPLITS")) : 14;   // x 36 tiles of 64 x 192 = 504 workgroups
+  static const int s_merge_env = getenv("ROVIT_WGRAD_MERGE_SPLITS") ? atoi(getenv("ROVIT_WGRAD_MERGE_SPLITS")) : 16;   // x 12 tiles of 192 x 192 = 192 workgroups
   static const bool merge_env = !(getenv("ROVIT_WGRAD_MERGE") && getenv("ROVIT_WGRAD_MERGE")[0] == '0');
   // never more splits than the slab buffers were sized for (small batches have few 64-row steps)
   const int S_MERGE = std::min(std::min(s_merge_env, L.s_fc1), std::min(std::min(L.s_fc2, L.s_qkv), L.s_proj));

@@ -21,16 +21,16 @@ OUT = os.path.join(ROOT, 'gpurun_out', 'pmc_r03')
 
 # (substring of rocprof's Kernel_Name, occurrence group ordered by first dispatch when the same kernel runs two shapes, key)
 KERNELS = [
-    ('wgrad_kernel<64, 192, false, false>', 0, 'wgrad_kernel<64,192,false>'),
+    ('wgrad_kernel<192, 192, false, false, 4>', 0, 'wgrad_kernel<192,192>'),
     ('gemm_ws_dma_kernel<0>', 0, 'qkv_fwd'),
     ('gemm_ws_dma_kernel<0>', 1, 'proj_dgrad'),
     ('attn_fwd_kernel', 0, 'attention_fwd'),
     ('attn_bwd_kernel', 0, 'attention_bwd'),
     ('gemm_ws_kernel<6, 1, 64, 5>', 0, 'proj_fwd_resid_ln'),
     ('gemm_kdma_kernel<18, 6>', 0, 'qkv_dgrad_ln_bwd'),
-    ('mlp_fused_kernel<0, 2, 8>', 0, 'mlp_fused_fwd_train'),
-    ('mlp_fused_kernel<0, 0, 8>', 0, 'mlp_fused_fwd_inference'),
-    ('mlp_fused_kernel<1, 1, 8>', 0, 'mlp_fused_bwd'),
+    ('mlp_fused_kernel<0, 2, 8, false>', 0, 'mlp_fused_fwd_train'),
+    ('mlp_fused_kernel<0, 0, 8, false>', 0, 'mlp_fused_fwd_inference'),
+    ('mlp_fused_kernel<1, 1, 8, false>', 0, 'mlp_fused_bwd'),
     ('kan_fwd_kernel', 0, 'kan_fwd_kernel'),
     ('kan_stack_mfma_kernel<4, 4', 0, 'kan_stack_mfma_kernel<4>'),
     ('kan_stack_mfma_kernel<18, 1', 0, 'kan_stack_mfma_kernel<18>'),

@@ -204,6 +204,9 @@ int rovit_set_mlp_debug(int bits);
 int rovit_set_attn_debug(int bits);
 /* developer knob: rovit_attention_bwd as persistent workgroups with LDS-DMA prefetch (1) or the staged kernel (0, default: faster); bit-identical results */
 int rovit_set_attn_bwd_pipe(int on);
+/* token rows (batch x 197) from which rovit_vit_forward / rovit_vit_backward use rovit_mlp_fused_fwd / _bwd instead of the two-launch
+ * MLP half (default 34000 = batch 173, the measured crossover; environment ROVIT_MLP_FUSED_MIN_ROWS); 0 = always fused */
+int rovit_set_mlp_fused_min_rows(int rows);
 /* developer knob (A/B timing): waves per workgroup of rovit_mlp_fused_fwd, 8 = one 256-row workgroup per CU (default), 4 = two 128-row
  * ones, 9 = 8 waves with waves 4-7 staggered half a chunk behind waves 0-3 */
 int rovit_set_mlp_waves(int waves);

@@ -36,6 +36,12 @@ inline bool recompute_gelu() {
   return on;
 }
 
+// token rows (batch x 197) from which the one-launch MLP half (mlp_fused.hip) is used; below it the two-launch kernels.
+// Measured crossover on MI355X (tools/fwd_small_batch.py, bench.py --batch n): batch 176 for the inference forward (1.52 ms
+// either way; batch 128: 1.33 fused against 1.23 ms, batch 1: 0.99 against 0.66 ms) and for the training step alike.
+int g_mlp_fused_min_rows = [] { const char* e = getenv("ROVIT_MLP_FUSED_MIN_ROWS"); return e ? atoi(e) : 34000; }();
+inline int mlp_fused_min_rows() { return g_mlp_fused_min_rows; }
+
 struct Prep {          // byte offsets into the prepared-weight buffer
   size_t wpe;
   size_t blk0, blk_stride;
@@ -190,6 +196,13 @@ int check_common(const void* params, const void* prep, const void* ws, int batch
 
 }  // namespace
 
+// token rows (batch x 197) from which rovit_vit_forward / rovit_vit_backward use the one-launch MLP half; 0 = always, a huge value = never
+extern "C" int rovit_set_mlp_fused_min_rows(int rows) {
+  ROVIT_CHECK_ARG(rows >= 0, ROVIT_ERR_SHAPE, "set_mlp_fused_min_rows: rows >= 0 (got %d)", rows);
+  g_mlp_fused_min_rows = rows;
+  return ROVIT_OK;
+}
+
 extern "C" size_t rovit_vit_prep_bytes(int depth) { return Prep(depth).total; }
 extern "C" size_t rovit_vit_workspace_bytes(int batch, int depth, int training) { return Plan(batch, depth, training).total; }
 extern "C" int rovit_vit_num_params(int depth) { return P_BLOCK0 + B_COUNT * depth; }
@@ -326,8 +339,10 @@ int vit_forward_impl(const float* images, const float* const* params, const void
     }
     // MLP half: one launch (fc1 + GELU + fc2 + residual + next LayerNorm, mlp_fused.hip); `act` is never re-read, and an
     // inference call keeps neither act nor gelu'.  ROVIT_MLP_FUSED=0: the two-launch path (A/B timing).
+    // A fused launch has one workgroup per 256 rows: below ROVIT_MLP_FUSED_MIN_ROWS rows (small batches) it leaves most of the
+    // chip idle and the two-launch path, whose grids also split the output columns, is faster.
     static const bool mlp_fused = !(getenv("ROVIT_MLP_FUSED") && getenv("ROVIT_MLP_FUSED")[0] == '0');
-    if (mlp_fused && !cls_only) {
+    if (mlp_fused && !cls_only && batch * T >= mlp_fused_min_rows()) {
       char* sn = ws + L.blk0 + (size_t)(i + 1) * L.blk_stride;            // next block's saved-activation area
       EACH_HALF {
         const Half& h = halves[hh];
@@ -542,7 +557,7 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
     // A1 + A2 in one launch (mlp_fused.hip): fc2 dgrad x gelu' -> dpre (kept for B2), fc1 dgrad + norm2 backward without
     // re-reading dpre.  ROVIT_MLP_BWD_FUSED=0: the two launches (A/B timing); the gelu'-recompute memory mode keeps them too.
     static const bool mlp_bwd_fused = !(getenv("ROVIT_MLP_BWD_FUSED") && getenv("ROVIT_MLP_BWD_FUSED")[0] == '0');
-    if (mlp_bwd_fused && !recompute_gelu()) {
+    if (mlp_bwd_fused && !recompute_gelu() && M >= mlp_fused_min_rows()) {
       RUN(rovit_mlp_fused_bwd(xin, q + P.wmlpb, s + L.dact, dp, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmid, M, sA));
     } else {
       if (recompute_gelu())                                                                                            // A1

@@ -59,6 +59,7 @@ SIGNATURES = {
     'rovit_set_mlp_debug': (_i, [_i]),
     'rovit_set_attn_debug': (_i, [_i]),
     'rovit_set_attn_bwd_pipe': (_i, [_i]),
+    'rovit_set_mlp_fused_min_rows': (_i, [_i]),
     'rovit_gemm_ln_bwd': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'rovit_set_gemm_tile': (_i, [_i]),
     'rovit_set_gemm_debug': (_i, [_i]),

@@ -25,6 +25,16 @@ def dev():
     return torch.device('cuda:0')
 
 
+@pytest.fixture(params=['fused_mlp_half', 'two_launch_mlp_half'])
+def mlp_half(request):
+    """rovit_vit_forward / _backward pick the MLP-half kernels by batch size (one fused launch from 34 000 token rows, two launches
+    below): the small parity cases run under BOTH so that the path of the benchmark batch is checked against the oracle too."""
+    from rovit_hip import native
+    native.call('rovit_set_mlp_fused_min_rows', 0 if request.param == 'fused_mlp_half' else 1 << 30)
+    yield request.param
+    native.call('rovit_set_mlp_fused_min_rows', 34000)
+
+
 def _vit(depth, sd):
     from models.backbone import DeiTTiny
     m = DeiTTiny(depth)
@@ -33,7 +43,7 @@ def _vit(depth, sd):
 
 
 @pytest.mark.parametrize('name', ['vit_depth2', 'vit_depth12'])
-def test_backbone_forward_vs_hf_golden(golden_dir, name):
+def test_backbone_forward_vs_hf_golden(golden_dir, name, mlp_half):
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     depth, batch, seed = int(g['depth']), int(g['batch']), int(g['seed'])
     gen = torch.Generator().manual_seed(seed)
@@ -54,7 +64,7 @@ def test_backbone_forward_vs_hf_golden(golden_dir, name):
     assert float((f - torch.from_numpy(g['features'])).abs().max()) < BF16_TOL
 
 
-def test_backbone_backward_vs_oracle():
+def test_backbone_backward_vs_oracle(mlp_half):
     depth, B = 2, 3
     gen = torch.Generator().manual_seed(21)
     sd = ref_cpu.init_vit_state(depth, gen)
@@ -153,7 +163,7 @@ def test_full_model_forward_all_stages_vs_oracle():
         m.curriculum_stage = 5
 
 
-def test_full_model_joint_loss_backward_vs_oracle():
+def test_full_model_joint_loss_backward_vs_oracle(mlp_half):
     sd = ref_cpu.init_rovit_state(depth=12, seed=4)
     torch.manual_seed(1)
     B = 4
@@ -312,7 +322,7 @@ def test_attention_output_taps_vs_oracle():
     assert float((f_plain.cpu() - ref_f).abs().max()) < BF16_TOL
 
 
-def test_two_stream_schedule_vs_oracle_and_on_a_side_stream():
+def test_two_stream_schedule_vs_oracle_and_on_a_side_stream(mlp_half):
     """B >= 16 takes the two-stream schedule (half-batch forward chains, dgrad/wgrad backward streams): depth 4 so
     that every rotating hand-over buffer of the backward is reused at least once.  Checked against the oracle, and
     the same step launched from a non-default torch stream must reproduce it bit for bit (the default stream is the
@@ -351,7 +361,7 @@ def test_two_stream_schedule_vs_oracle_and_on_a_side_stream():
         assert torch.equal(p.grad, g0[k]), k
 
 
-def test_bucketed_grad_sync_one_rank_matches_plain_backward():
+def test_bucketed_grad_sync_one_rank_matches_plain_backward(mlp_half):
     """GradSync with the RCCL process group of ONE rank (collectives forced): block-range backward with the deferred
     join (rovit_vit_backward_notify) + all-reduce on the side stream must leave exactly the gradients of the plain
     backward (AVG over one rank is the identity)."""

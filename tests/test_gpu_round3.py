@@ -319,7 +319,7 @@ torch.save({'f': f.detach().cpu(), 'g': g.cpu()}, out)
     with tempfile.TemporaryDirectory() as td:
         for mode in ('1', '0'):
             out = os.path.join(td, f'o{mode}.pt')
-            env = dict(os.environ, ROVIT_MLP_FUSED=mode, ROVIT_MLP_BWD_FUSED=mode)
+            env = dict(os.environ, ROVIT_MLP_FUSED=mode, ROVIT_MLP_BWD_FUSED=mode, ROVIT_MLP_FUSED_MIN_ROWS='0')
             subprocess.run([sys.executable, '-c', code, out, root, pkg], check=True, env=env, timeout=600)
             res[mode] = torch.load(out, weights_only=True)
     f1, f0 = res['1']['f'], res['0']['f']

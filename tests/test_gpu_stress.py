@@ -75,24 +75,41 @@ def test_two_stream_forward_equals_small_batch_chunks(B):
     (any cross-stream ordering bug or row-offset mistake shows up as a difference), and the gradients of a sum-type
     loss must equal the sum of the chunk gradients (different summation order: 2e-3 of the largest entry)."""
     from models.backbone import DeiTTiny
+    from rovit_hip import native
     torch.manual_seed(B)
     m = DeiTTiny(3).to(dev())
     x = torch.randn(B, 3, 224, 224, device=dev())
     w = torch.randn(B, 192, device=dev())
-    f = m(x)
-    (f * w).sum().backward()
-    g_big = {n: p.grad.clone() for n, p in m.named_parameters()}
-    for p in m.parameters():
-        p.grad = None
-    feats = []
-    for i in range(0, B, 8):
-        fc = m(x[i:i + 8])
-        (fc * w[i:i + 8]).sum().backward()                   # accumulates into the engine-owned gradients
-        feats.append(fc.detach())
-    assert torch.equal(f.detach(), torch.cat(feats))
-    for n, p in m.named_parameters():
-        scale = float(g_big[n].abs().max()) + 1e-12
-        assert float((p.grad - g_big[n]).abs().max()) <= 2e-3 * scale, n
+    # Round 3: from 34 000 token rows (batch 173) the MLP half is ONE launch whose fc2 sums the 768 hidden units in one chain; the
+    # two-launch kernels of smaller batches sum two halves.  Bit equality therefore holds between batches on the same side of
+    # that threshold: B = 255 pins the one-launch kernels for its 8-image chunks too, and is then also compared, to rounding,
+    # with the chunks on the default (two-launch) side.
+    big = B * 197 >= 34000
+    if big:
+        native.call('rovit_set_mlp_fused_min_rows', 0)
+    try:
+        f = m(x)
+        (f * w).sum().backward()
+        g_big = {n: p.grad.clone() for n, p in m.named_parameters()}
+        for p in m.parameters():
+            p.grad = None
+        feats = []
+        for i in range(0, B, 8):
+            fc = m(x[i:i + 8])
+            (fc * w[i:i + 8]).sum().backward()                   # accumulates into the engine-owned gradients
+            feats.append(fc.detach())
+        assert torch.equal(f.detach(), torch.cat(feats))
+        for n, p in m.named_parameters():
+            scale = float(g_big[n].abs().max()) + 1e-12
+            assert float((p.grad - g_big[n]).abs().max()) <= 2e-3 * scale, n
+    finally:
+        native.call('rovit_set_mlp_fused_min_rows', 34000)
+    if big:
+        with torch.no_grad():
+            f2 = torch.cat([m(x[i:i + 8]) for i in range(0, B, 8)])
+        d = (f2 - f.detach()).abs()
+        print('one-launch vs two-launch MLP half, features: max', float(d.max()), 'rms', float(d.pow(2).mean().sqrt()))
+        assert float(d.max()) < 3e-2 and float(d.pow(2).mean().sqrt()) < 6e-3
 
 
 def test_training_trajectory_is_bit_reproducible():

@@ -193,10 +193,10 @@ def mlp_roofline(dev):
     res = {}
     res['fused_fwd_train'] = _entry(dev, lambda: lib.rovit_mlp_fused_fwd(p(xhat2), p(ws), p(b1), p(b2), p(act), p(dact), p(X), p(xhat), p(rstd), 1e-6, M, sp),
                                     2.0 * M * 192 * 2 + 2.0 * M * 768 * 2 + 8.0 * M * 192 + 4.0 * M + wbytes, 4.0 * M * 768 * 192,
-                                    'mlp_fused_kernel<0,2,8>: fc1 + GELU + fc2 + residual + LayerNorm, act and gelu\' kept, M=50432', 'mlp_fused_fwd_train')
+                                    'mlp_fused_kernel<0,2,8,false,true> (in-wave pipeline, GELU table): fc1 + GELU + fc2 + residual + LayerNorm, act and gelu\' kept, M=50432', 'mlp_fused_fwd_train')
     res['fused_fwd_inference'] = _entry(dev, lambda: lib.rovit_mlp_fused_fwd(p(xhat2), p(ws), p(b1), p(b2), None, None, p(X), p(xhat), p(rstd), 1e-6, M, sp),
                                         2.0 * M * 192 * 2 + 8.0 * M * 192 + 4.0 * M + wbytes, 4.0 * M * 768 * 192,
-                                        'mlp_fused_kernel<0,0,8>: the same, nothing kept (inference)', 'mlp_fused_fwd_inference')
+                                        'mlp_fused_kernel<0,0,8,false,true>: the same, nothing kept (inference)', 'mlp_fused_fwd_inference')
     dact.uniform_(0, 1)
     res['fused_bwd'] = _entry(dev, lambda: lib.rovit_mlp_fused_bwd(p(dY), p(wsb), p(dact), p(dpre), p(xhat2), p(rstd), p(dX), p(dXb), M, sp),
                               2.0 * M * 192 * 3 + 2.0 * M * 768 * 2 + 8.0 * M * 192 + 4.0 * M + wbytes, 4.0 * M * 768 * 192,

@@ -207,8 +207,9 @@ int rovit_set_attn_bwd_pipe(int on);
 /* token rows (batch x 197) from which rovit_vit_forward / rovit_vit_backward use rovit_mlp_fused_fwd / _bwd instead of the two-launch
  * MLP half (default 34000 = batch 173, the measured crossover; environment ROVIT_MLP_FUSED_MIN_ROWS); 0 = always fused */
 int rovit_set_mlp_fused_min_rows(int rows);
-/* developer knob (A/B timing): waves per workgroup of rovit_mlp_fused_fwd, 8 = one 256-row workgroup per CU (default), 4 = two 128-row
- * ones, 9 = 8 waves with waves 4-7 staggered half a chunk behind waves 0-3 */
+/* developer knob (A/B timing): schedule of rovit_mlp_fused_fwd, 8 = one 256-row workgroup of 8 waves per CU in lockstep, 4 = two 128-row
+ * ones, 9 = 8 waves with waves 4-7 staggered half a chunk behind waves 0-3, 10 = 8 waves, in-wave software pipeline (fc1 of chunk
+ * j under the GELU of chunk j - 1) with the GELU looked up in an LDS table of the bf16 input patterns (DEFAULT) */
 int rovit_set_mlp_waves(int waves);
 /* dgrad through a Linear that follows a LayerNorm, fused with that LayerNorm's backward:
  * dxhat = dY W^T;  dX += rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat));  dXb = bf16(dX) */

@@ -41,6 +41,13 @@
 #include <cstdlib>
 #include "common.h"
 
+#ifndef ROVIT_MLP_PIPE_HINTS
+#define ROVIT_MLP_PIPE_HINTS 0
+#endif
+#ifndef ROVIT_MLP_PIPE_SKEW
+#define ROVIT_MLP_PIPE_SKEW 1
+#endif
+
 namespace {
 
 constexpr int D = 192, HID = 768, HC = 32, NCHUNK = HID / HC;
@@ -48,6 +55,11 @@ constexpr int PIECE = 512;                    // bf16 elements of a 1 KB piece (
 constexpr int CH_PIECES = 24;                 // 12 first-GEMM fragments (2 tiles x 6 k-steps) + 12 second-GEMM fragments (12 output tiles)
 constexpr int CH_ELEMS = CH_PIECES * PIECE;   // 24 KB of weights per chunk
 constexpr int NSLOT = 3;
+// pipelined forward: ring entry j carries the fc2 fragments of hidden chunk j - PSKEW next to the fc1 fragments of chunk j.
+// PSKEW = 2: iteration j issues fc1 of chunk j, the GELU look-ups of chunk j - 1 and fc2 of chunk j - 2 -- three mutually
+// independent streams of work (matrix, vector + LDS gather, matrix); 1: fc2 of chunk j - 1 behind its own GELU.
+constexpr int PSKEW = ROVIT_MLP_PIPE_SKEW;
+constexpr int PENTRIES = NCHUNK + PSKEW;
 constexpr int CSTR = 192 + 8;                 // staged output tile [ROWS][CSTR] bf16
 // NW waves per workgroup, 32 rows per wave.  NW = 8: one 256-row workgroup per CU.  NW = 4 (forward only): 128-row workgroups,
 // two per CU (76 KB each).  A backward slot also holds the workgroup's gelu' tile of the chunk (2 NW pieces).
@@ -55,6 +67,12 @@ constexpr int slot_elems(int kind, int nw) { return CH_ELEMS + (kind ? 2 * nw * 
 constexpr int region_elems(int kind, int nw) {      // ring / staged tile (aliased)
   return NSLOT * slot_elems(kind, nw) > 32 * nw * CSTR ? NSLOT * slot_elems(kind, nw) : 32 * nw * CSTR;
 }
+// GELU table of the pipelined forward.  The GELU input is the bf16-rounded pre-activation, so gelu / gelu' are functions of a 16-bit
+// pattern: for 2^-24 <= |x| < 16 (28 exponents x 128 mantissas x 2 signs) the pair (bf16 gelu, bf16 gelu') is looked up in a 32 KB
+// LDS table that the weight preparation fills WITH gelu_and_grad itself (bit-identical by construction); any other input (zero,
+// denormal-small, huge, NaN) takes the formula under a wave-uniform branch.  Entry of pattern u: index ((u & 0x7FFF) - GT_EM_LO),
+// negative inputs 4096 entries further.
+constexpr int GT_EM_LO = (127 - 24) << 7, GT_N = 28 << 7, GT_NEG = 4096, GT_ENTRIES = 8192;
 constexpr size_t lds_bytes(int kind, int nw) { return (size_t)region_elems(kind, nw) * sizeof(bf16) + (HID + D) * sizeof(float); }
 
 struct MlpArgs {
@@ -65,6 +83,7 @@ struct MlpArgs {
   bf16* act;              // forward (M,768) gelu(pre) (MODE >= 1); backward (M,768) dpre (output)
   bf16* dact;             // forward (M,768) gelu'(pre) (MODE == 2)
   const bf16* mul;        // backward (M,768) gelu'(pre)
+  const bf16* gelu_table; // pipelined forward: the 32 KB table behind the two stream images
   float* X;               // (M,192) forward: residual stream; backward: dX; updated in place
   bf16* xhat;             // forward: next LayerNorm output or NULL; backward: xhat2 (input)
   float* rstd;            // forward: (M) output; backward: rstd2 (input)
@@ -75,6 +94,7 @@ struct MlpArgs {
 };
 
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -91,9 +111,17 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // FOUR slots: 96 KB, still under the staged output tile it aliases), issue out-of-range (dropped, but counted) stores in
 // their first iteration so that the vmcnt arithmetic is the same for every wave, and finish chunk 23 behind the loop.
 // Outputs are bit-identical to the unstaggered kernel (same operations on the same values, per wave in the same order).
-template <int KIND, int MODE, int NW, bool STAG = false>
+// PIPE (forward, 8 waves): software pipeline INSIDE each wave.  The weight stream is the SKEWED image (ring entry j = fc1 fragments of
+// hidden chunk j | fc2 fragments of hidden chunk j - PSKEW, PENTRIES entries), so iteration j issues the fc1 MFMAs of chunk j,
+// the GELU of chunk j - 1 (whose pre-activations were packed to bf16 at the end of iteration j - 1) and the fc2 MFMAs of chunk
+// j - 2 (whose GELU output iteration j - 1 left in registers): nothing inside an iteration depends on anything else in it, so
+// the scheduler can put the vector work and the LDS gathers into the matrix pipe's shadow.  The GELU itself is a table look-up
+// (GT_*).  The first iterations' GELU / fc2 run on zeros and the last ones' fc1 on zero blocks; stores of chunks that do not
+// exist are sent out of range (dropped, but counted).
+template <int KIND, int MODE, int NW, bool STAG = false, bool PIPE = false>
 __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) {
   static_assert(!STAG || (KIND == 0 && NW == 8), "the staggered schedule is the 8-wave forward's");
+  static_assert(!PIPE || (KIND == 0 && NW == 8 && !STAG), "the pipelined schedule is the 8-wave forward's");
   constexpr int S = 2 * MODE;                 // stores one wave issues per chunk
   constexpr int ROWS = 32 * NW;               // rows per workgroup: wave w owns the 16-row tiles w and w + NW
   constexpr int PW = CH_PIECES / NW + (KIND ? 2 : 0);   // DMA pieces one wave issues per chunk
@@ -127,6 +155,14 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
                                          (__attribute__((address_space(3))) void*)(lds + slot * SLOT + (CH_PIECES + w + NW * i) * PIECE), 16, 0, 0);
     }
   };
+  const bf16* gtab = lds + region_elems(KIND, NW) + 2 * (HID + D);     // PIPE: the GELU table (behind the biases)
+  if constexpr (PIPE) {
+    const bf16* src = g.gelu_table + lane * 8;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)                                          // 32 pieces of 1 KB: 8 waves x 4 (older than the ring's first DMA)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (r * NW + w) * PIECE),
+                                       (__attribute__((address_space(3))) void*)(lds + region_elems(KIND, NW) + 2 * (HID + D) + (r * NW + w) * PIECE), 16, 0, 0);
+  }
   dma(0, 0);
   dma(1, 1);
 
@@ -278,6 +314,117 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
       mid();
       H1(NCHUNK);                                            // chunk 23's second half
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  } else if constexpr (PIPE) {
+    bf16x8 pk[2] = {};               // bf16(pre-activation) of chunk j - 1: tile i, elements 4 t + r
+    bf16x8 avo[2] = {};              // PSKEW = 2: gelu of chunk j - 2
+    int slot = 0;
+#pragma unroll 1
+    for (int j = 0; j < PENTRIES; ++j) {
+      // issue order per iteration: [DMA(j+2): PW] [stores(j-1): S]: the same counts as the lockstep loop with PENTRIES entries
+      if (j == 0) wait_vm<PW>();
+      else if (j == 1) wait_vm<PW + S>();
+      else if (j < PENTRIES - 1) wait_vm<PW + 2 * S>();
+      else wait_vm<2 * S>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (j + 2 < PENTRIES) dma(j + 2, slot == 0 ? 2 : slot - 1);
+      const bf16* sb = lds + slot * SLOT + lane * 8;
+      const int cb = j < NCHUNK ? j : NCHUNK - 1;             // bias row of a real chunk (the products of the last PSKEW iterations are discarded)
+      f32x4 a1[2][2];
+      {
+        const f32x4 ba = *(const f32x4*)(s_bias + cb * HC + 8 * lg), bb = *(const f32x4*)(s_bias + cb * HC + 8 * lg + 4);
+        a1[0][0] = ba; a1[0][1] = ba; a1[1][0] = bb; a1[1][1] = bb;
+      }
+      // ---- fc1 of chunk j (matrix pipe) ... ----
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) {
+        const bf16x8 wa = *(const bf16x8*)(sb + ks * PIECE), wb = *(const bf16x8*)(sb + (6 + ks) * PIECE);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a1[0][i] = mfma16(wa, xf[i][ks], a1[0][i]);
+          a1[1][i] = mfma16(wb, xf[i][ks], a1[1][i]);
+        }
+      }
+      // ---- ... with the GELU of chunk j - 1 in its shadow: table look-ups (a handful of integer operations and one 4-byte LDS
+      // gather per element instead of ~20 fp32 operations with two transcendentals: the lockstep kernel is VALU-bound on those) ----
+      bf16x8 av[2], dv[2];
+      {
+        unsigned t[2][8], ix[2][8];
+        unsigned mx = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const u32x4v pw = __builtin_bit_cast(u32x4v, pk[i]);
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const unsigned w32 = pw[d];
+            ix[i][2 * d] = (w32 & 0x7FFFu) - (unsigned)GT_EM_LO;
+            ix[i][2 * d + 1] = ((w32 >> 16) & 0x7FFFu) - (unsigned)GT_EM_LO;
+            mx = max(mx, max(ix[i][2 * d], ix[i][2 * d + 1]));
+            const unsigned a0 = (min(ix[i][2 * d], (unsigned)(GT_N - 1)) << 1) | ((w32 & 0x8000u) >> 2);        // in bf16 elements
+            const unsigned a1 = (min(ix[i][2 * d + 1], (unsigned)(GT_N - 1)) << 1) | ((w32 >> 18) & 0x2000u);
+            t[i][2 * d] = __builtin_bit_cast(unsigned, *(const bf16x2*)(gtab + a0));
+            t[i][2 * d + 1] = __builtin_bit_cast(unsigned, *(const bf16x2*)(gtab + a1));
+          }
+        }
+        if (__builtin_amdgcn_ballot_w64(mx >= (unsigned)GT_N)) {          // rare: some lane holds an input outside the table
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (ix[i][e] >= (unsigned)GT_N) {
+                float ga, gd;
+                gelu_and_grad((float)pk[i][e], ga, gd);
+                const bf16x2 pr = {(bf16)ga, (bf16)gd};
+                t[i][e] = __builtin_bit_cast(unsigned, pr);
+              }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          u32x4v a, dd;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            a[d] = __builtin_amdgcn_perm(t[i][2 * d + 1], t[i][2 * d], 0x05040100u);
+            dd[d] = __builtin_amdgcn_perm(t[i][2 * d + 1], t[i][2 * d], 0x07060302u);
+          }
+          av[i] = __builtin_bit_cast(bf16x8, a);
+          dv[i] = __builtin_bit_cast(bf16x8, dd);
+        }
+      }
+#if ROVIT_MLP_PIPE_HINTS
+#pragma unroll
+      for (int k = 0; k < 24; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+        if (k % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
+        __builtin_amdgcn_sched_group_barrier(0x002, ROVIT_MLP_PIPE_HINTS, 0);   // vector instructions
+      }
+#endif
+      if (MODE >= 1) {
+        const bool real = j >= 1 && j <= NCHUNK;                // no such chunk: an offset beyond num_records (no wrap-around: absolute)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const unsigned off = real ? soff[i] + (unsigned)(j - 1) * (HC * 2) : 0xFFFFFF00u;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, av[i]), r_act, off, 0, 0);
+          if (MODE == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dv[i]), r_dact, off, 0, 0);
+        }
+      }
+      // ---- fc2 of chunk j - PSKEW ----
+#pragma unroll
+      for (int ot = 0; ot < 12; ++ot) {
+        const bf16x8 w2 = *(const bf16x8*)(sb + (12 + ot) * PIECE);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a2[ot][i] = mfma16(w2, PSKEW == 2 ? avo[i] : av[i], a2[ot][i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        avo[i] = av[i];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pk[i][4 * t + r] = (bf16)a1[t][i][r];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      slot = slot == 2 ? 0 : slot + 1;
     }
   } else {
   int slot = 0;
@@ -490,24 +637,52 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
 //   piece 6 t + ks (t = 0, 1; ks = 0..5): lane (l15, lg) = W1f[32 c + 8 (l15 >> 2) + 4 t + (l15 & 3)][32 ks + 8 lg .. +7]
 //   piece 12 + ot  (ot = 0..11):         lane (l15, lg) = W2[16 ot + l15][32 c + 8 lg .. +7]
 struct MlpPrepArgs { const char* base; size_t blk0, stride, off_w1, off_w2, off_out; };
+// The stream buffer holds TWO images: the plain one (NCHUNK entries) and, behind it, the SKEWED one of the pipelined forward
+// (PENTRIES entries: entry j = fc1 fragments of chunk j | fc2 fragments of chunk j - PSKEW; the missing halves are zeros).
+constexpr int STREAM_ENTRIES = NCHUNK + PENTRIES;
 __global__ __launch_bounds__(256) void mlp_stream_prep_kernel(const MlpPrepArgs a) {
   const int blk = blockIdx.y;
   const char* q = a.base + a.blk0 + (size_t)blk * a.stride;
   const bf16* w1 = (const bf16*)(q + a.off_w1);
   const bf16* w2 = (const bf16*)(q + a.off_w2);
   bf16* out = (bf16*)(const_cast<char*>(q) + a.off_out);
-  const int e = blockIdx.x * 256 + threadIdx.x;          // 16-byte element of the stream: NCHUNK * 24 * 64
-  if (e >= NCHUNK * CH_PIECES * 64) return;
-  const int lane = e & 63, piece = (e >> 6) % CH_PIECES, c = e / (64 * CH_PIECES);
+  const int e = blockIdx.x * 256 + threadIdx.x;          // 16-byte element of the stream: STREAM_ENTRIES * 24 * 64
+  if (e >= STREAM_ENTRIES * CH_PIECES * 64) return;
+  const int lane = e & 63, piece = (e >> 6) % CH_PIECES, entry = e / (64 * CH_PIECES);
   const int l15 = lane & 15, lg = lane >> 4;
-  const bf16* src;
-  if (piece < 12) {
-    const int t = piece / 6, ks = piece - 6 * t;
-    src = w1 + (size_t)(HC * c + 8 * (l15 >> 2) + 4 * t + (l15 & 3)) * D + 32 * ks + 8 * lg;
-  } else {
-    src = w2 + (size_t)(16 * (piece - 12) + l15) * HID + HC * c + 8 * lg;
+  int c = entry;                                          // hidden chunk this piece belongs to
+  if (entry >= NCHUNK) c = entry - NCHUNK - (piece < 12 ? 0 : PSKEW);
+  bf16x8 v = {};
+  if (c >= 0 && c < NCHUNK) {
+    const bf16* src;
+    if (piece < 12) {
+      const int t = piece / 6, ks = piece - 6 * t;
+      src = w1 + (size_t)(HC * c + 8 * (l15 >> 2) + 4 * t + (l15 & 3)) * D + 32 * ks + 8 * lg;
+    } else {
+      src = w2 + (size_t)(16 * (piece - 12) + l15) * HID + HC * c + 8 * lg;
+    }
+    v = *(const bf16x8*)src;
   }
-  *(bf16x8*)(out + (size_t)e * 8) = *(const bf16x8*)src;
+  *(bf16x8*)(out + (size_t)e * 8) = v;
+}
+
+// the GELU table (see GT_*): entry = bf16 gelu | bf16 gelu' << 16 of the bf16 input pattern, computed by gelu_and_grad itself
+__global__ __launch_bounds__(256) void mlp_gelu_table_kernel(const MlpPrepArgs a) {
+  const char* q = a.base + a.blk0 + (size_t)blockIdx.y * a.stride;
+  unsigned* out = (unsigned*)(const_cast<char*>(q) + a.off_out + (size_t)STREAM_ENTRIES * CH_ELEMS * sizeof(bf16));
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= GT_ENTRIES) return;
+  const int k = e & (GT_NEG - 1);
+  unsigned v = 0;
+  if (k < GT_N) {
+    const unsigned short u = (unsigned short)((e >= GT_NEG ? 0x8000 : 0) | (GT_EM_LO + k));
+    const bf16 x = __builtin_bit_cast(bf16, u);
+    float ga, gd;
+    gelu_and_grad((float)x, ga, gd);
+    const bf16x2 pr = {(bf16)ga, (bf16)gd};
+    v = __builtin_bit_cast(unsigned, pr);
+  }
+  out[e] = v;
 }
 
 }  // namespace
@@ -523,23 +698,31 @@ static int g_mlp_waves = [] { const char* e = getenv("ROVIT_MLP_WAVES"); return 
 // chunk and the LDS-resident fragments give 5 us back: 68 against 71 us on one box, 76 against 75 on another.  Not a robust
 // win, so the simpler lockstep kernel stays the default.
 static int g_mlp_stagger = [] { const char* e = getenv("ROVIT_MLP_STAGGER"); return (e && e[0] == '1') ? 1 : 0; }();
+// in-wave pipeline + GELU table (see the kernel): the DEFAULT since it was measured (MI355X, M = 50 432): 64.2 against 75.0 us per
+// training launch, 56.9 against 66.8 us per inference launch, batch-256 inference forward 1.58 against 1.69 ms; inside the training
+// step, where the forward is bound by the act / gelu' stores of two concurrent half-batch chains, 5.39 against 5.41 ms.
+// ROVIT_MLP_PIPE=0 / rovit_set_mlp_waves(8): the lockstep kernel.
+static int g_mlp_pipe = [] { const char* e = getenv("ROVIT_MLP_PIPE"); return (e && e[0] == '0') ? 0 : 1; }();
 extern "C" int rovit_set_mlp_waves(int nw) {
-  ROVIT_CHECK_ARG(nw == 4 || nw == 8 || nw == 9, ROVIT_ERR_SHAPE, "set_mlp_waves: 4, 8 or 9 (= 8 waves, staggered) (got %d)", nw);
+  ROVIT_CHECK_ARG(nw == 4 || nw == 8 || nw == 9 || nw == 10, ROVIT_ERR_SHAPE,
+                  "set_mlp_waves: 4, 8, 9 (= 8 waves, staggered) or 10 (= 8 waves, in-wave pipeline) (got %d)", nw);
   g_mlp_stagger = nw == 9;
-  g_mlp_waves = nw == 9 ? 8 : nw;
+  g_mlp_pipe = nw == 10;
+  g_mlp_waves = nw >= 9 ? 8 : nw;
   return ROVIT_OK;
 }
 
 static int g_mlp_dbg = 0;
 extern "C" int rovit_set_mlp_debug(int bits) { g_mlp_dbg = bits; return ROVIT_OK; }
 
-extern "C" size_t rovit_mlp_stream_bytes(void) { return (size_t)NCHUNK * CH_ELEMS * sizeof(bf16); }
+extern "C" size_t rovit_mlp_stream_bytes(void) { return (size_t)STREAM_ENTRIES * CH_ELEMS * sizeof(bf16) + GT_ENTRIES * sizeof(unsigned); }
 
 // (internal) streams of `depth` blocks laid out inside the prepared-weight buffer of rovit_vit_prepare
 int rovit_mlp_stream_prep_blocks(const void* prep_base, size_t blk0, size_t stride, size_t off_w1, size_t off_w2, size_t off_out,
                                  int depth, rovit_stream_t stream) {
   const MlpPrepArgs a{(const char*)prep_base, blk0, stride, off_w1, off_w2, off_out};
-  hipLaunchKernelGGL(mlp_stream_prep_kernel, dim3(NCHUNK * CH_PIECES * 64 / 256, depth), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(mlp_stream_prep_kernel, dim3((STREAM_ENTRIES * CH_PIECES * 64 + 255) / 256, depth), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(mlp_gelu_table_kernel, dim3(GT_ENTRIES / 256, depth), dim3(256), 0, (hipStream_t)stream, a);
   ROVIT_CHECK_LAUNCH("mlp_stream_prep_kernel");
   return ROVIT_OK;
 }
@@ -551,7 +734,8 @@ extern "C" int rovit_mlp_prepare_stream(const void* w1f, const void* w2, void* w
   ROVIT_CHECK_ARG(rovit_aligned16(w1f) && rovit_aligned16(w2) && rovit_aligned16(wstream), ROVIT_ERR_ALIGN, "mlp_prepare_stream: alignment");
   // one "block" whose three fields are addressed relative to w1f
   const MlpPrepArgs a{(const char*)w1f, 0, 0, 0, (size_t)((const char*)w2 - (const char*)w1f), (size_t)((char*)wstream - (const char*)w1f)};
-  hipLaunchKernelGGL(mlp_stream_prep_kernel, dim3(NCHUNK * CH_PIECES * 64 / 256, 1), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(mlp_stream_prep_kernel, dim3((STREAM_ENTRIES * CH_PIECES * 64 + 255) / 256, 1), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(mlp_gelu_table_kernel, dim3(GT_ENTRIES / 256, 1), dim3(256), 0, (hipStream_t)stream, a);
   ROVIT_CHECK_LAUNCH("mlp_stream_prep_kernel");
   return ROVIT_OK;
 }
@@ -579,7 +763,18 @@ extern "C" int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const
                     "mlp_fused_fwd: cannot raise the LDS limit");                                                                \
     hipLaunchKernelGGL((mlp_fused_kernel<0, MD, NWV>), grid, block, lds_bytes(0, NWV), st, g);                                   \
   } while (0)
-  if (nw == 8 && g_mlp_stagger) {
+  if (nw == 8 && g_mlp_pipe) {
+    g.gelu_table = g.wstream + (size_t)STREAM_ENTRIES * CH_ELEMS;
+    g.wstream += (size_t)NCHUNK * CH_ELEMS;                // the skewed image
+#define LAUNCH_PIPE(MD)                                                                                                          \
+  do {                                                                                                                           \
+    ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<0, MD, 8, false, true>, lds_bytes(0, 8) + GT_ENTRIES * 4),   \
+                    ROVIT_ERR_LAUNCH, "mlp_fused_fwd: cannot raise the LDS limit");                                              \
+    hipLaunchKernelGGL((mlp_fused_kernel<0, MD, 8, false, true>), grid, block, lds_bytes(0, 8) + GT_ENTRIES * 4, st, g);         \
+  } while (0)
+    if (!act) LAUNCH_PIPE(0); else if (!dact) LAUNCH_PIPE(1); else LAUNCH_PIPE(2);
+#undef LAUNCH_PIPE
+  } else if (nw == 8 && g_mlp_stagger) {
 #define LAUNCH_STAG(MD)                                                                                                          \
   do {                                                                                                                           \
     ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<0, MD, 8, true>, lds_bytes(0, 8) + 8 * 6 * 1024), ROVIT_ERR_LAUNCH, \

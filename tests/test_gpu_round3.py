@@ -66,7 +66,7 @@ def _fused(native, xhat2, w1, w2, b1, b2, X0, mode=2, ln=True, waves=None):
     return act, dact, X, xhat, rstd
 
 
-@pytest.mark.parametrize('waves', [4, 8, 9])       # 8 = lockstep (default), 9 = the same 8 waves with waves 4-7 staggered by half a chunk
+@pytest.mark.parametrize('waves', [4, 8, 9, 10])   # 8 = lockstep, 9 = waves 4-7 staggered by half a chunk, 10 = in-wave pipeline + GELU table
 @pytest.mark.parametrize('M', [1, 5, 129, 197, 256, 257, 591, 1000, 3 * 197 * 4, 256 * 197])
 def test_fused_mlp_half_equals_the_two_launch_path_and_a_torch_reference(M, waves):
     """rovit_mlp_fused_fwd = rovit_gemm_nt(EPI_GELU) + rovit_gemm_resid_ln in one launch.  act and gelu' must be BIT-IDENTICAL to the
@@ -77,7 +77,7 @@ def test_fused_mlp_half_equals_the_two_launch_path_and_a_torch_reference(M, wave
     prob = _mlp_problem(M, 100 + M)
     a0, d0, X0, h0, r0 = _two_launch(native, *prob)
     a1, d1, X1, h1, r1 = _fused(native, *prob, waves=waves)
-    native.call('rovit_set_mlp_waves', 8)      # the library default
+    native.call('rovit_set_mlp_waves', 10)     # the library default
     assert torch.equal(a0.view(torch.int16), a1.view(torch.int16))
     assert torch.equal(d0.view(torch.int16), d1.view(torch.int16))
     xhat2, w1, w2, b1, b2, Xin = prob
@@ -95,6 +95,39 @@ def test_fused_mlp_half_equals_the_two_launch_path_and_a_torch_reference(M, wave
     ref_act.sum().backward()
     assert float((a1.float() - ref_act.detach()).abs().max()) < 3e-2
     assert float((d1.float() - pre.grad).abs().max()) < 1e-2
+
+
+@pytest.mark.parametrize('M', [64, 700])
+def test_pipelined_mlp_half_gelu_table_and_its_fallback_on_special_inputs(M):
+    """The pipelined forward looks gelu / gelu' up in a table of the bf16 input patterns 2^-24 <= |x| < 16 and falls back to the
+    formula (wave-uniform branch) elsewhere.  Drive pre-activations onto the table's edges and beyond: zero weights with biases
+    set to exact zeros, +-2^-24 (first entry), values below it, +-16 (first value above), huge values, and ordinary ones -- act and
+    gelu' must stay BIT-IDENTICAL to the two-launch kernels, which evaluate the formula for every element."""
+    native = _native()
+    xhat2, w1, w2, b1, b2, X0 = _mlp_problem(M, 900 + M)
+    w1 = torch.zeros_like(w1)                    # pre-activation = bias exactly
+    special = torch.tensor([0.0, -0.0, 2.0 ** -24, -2.0 ** -24, 2.0 ** -25, -2.0 ** -30, 1e-38, 15.9375, -15.9375, 16.0, -16.0, 40.0, -40.0, 3e4,
+                            -3e4, 1.0, -1.0, 0.5, 2.0 ** -23, 2.0 ** -10, -2.0 ** -10, 7.96875, 1e-45, -1e-45], device=dev())
+    b1 = special[torch.arange(768, device=dev()) % special.numel()].clone()
+    b1[400:] = (torch.randn(368, device=dev()) * 3)          # and a block of ordinary values
+    prob = (xhat2, w1, w2, b1, b2, X0)
+    a0, d0, Xr, h0, r0 = _two_launch(native, *prob)
+    a1, d1, X1, h1, r1 = _fused(native, *prob, waves=10)
+    native.call('rovit_set_mlp_waves', 10)
+    assert torch.equal(a0.view(torch.int16), a1.view(torch.int16))
+    assert torch.equal(d0.view(torch.int16), d1.view(torch.int16))
+    assert bool(torch.isfinite(X1).all())
+    # mixed case: real weights, a few bias columns special (most waves take the table, some the fallback)
+    xhat2, w1, w2, b1, b2, X0 = _mlp_problem(M, 901 + M)
+    w1[::7] = 0
+    b1[::7] = special[torch.arange(0, 768, 7, device=dev()) % special.numel()]
+    prob = (xhat2, w1, w2, b1, b2, X0)
+    a0, d0, Xr, h0, r0 = _two_launch(native, *prob)
+    a1, d1, X1, h1, r1 = _fused(native, *prob, waves=10)
+    native.call('rovit_set_mlp_waves', 10)
+    assert torch.equal(a0.view(torch.int16), a1.view(torch.int16))
+    assert torch.equal(d0.view(torch.int16), d1.view(torch.int16))
+    assert float((X1 - Xr).abs().max()) < 2 ** -7 * max(float((X1 - X0).abs().max()), 1.0)
 
 
 @pytest.mark.parametrize('M', [300, 197 * 16])

@@ -45,7 +45,7 @@ def main():
             fn()
         return run
     variants = {'two_launch': two}
-    for nw in (8, 9, 4):
+    for nw in (8, 10, 9, 4):
         variants[f'fused_train_w{nw}'] = with_waves(nw, fused(2))
         variants[f'fused_act_only_w{nw}'] = with_waves(nw, fused(1))
         variants[f'fused_inference_w{nw}'] = with_waves(nw, fused(0))
@@ -90,7 +90,7 @@ def main():
             res[k].append(round(timed(fn), 2))
     base = 8.0 * M * 192 + 2.0 * M * 192 + 2.0 * M * 192          # X read + write, xhat out, xhat2 in
     alg = {'two_launch': base + 2.0 * M * 768 * 3}
-    for nw in (8, 9, 4):
+    for nw in (8, 10, 9, 4):
         alg[f'fused_train_w{nw}'] = base + 2.0 * M * 768 * 2
         alg[f'fused_act_only_w{nw}'] = base + 2.0 * M * 768
         alg[f'fused_inference_w{nw}'] = base

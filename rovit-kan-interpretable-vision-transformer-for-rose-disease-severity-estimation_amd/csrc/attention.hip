@@ -203,15 +203,30 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const AttnArgs a) {
     }
     d += __shfl_xor(d, 1);
     if (half == 0) {
-      s_del[row] = d * a.scale;                 // pre-scaled: dS = P * (dP*scale - delta*scale)
-      s_lse[row] = row < a.T ? a.lse2[((size_t)b * a.H + h) * a.T + row] : 0.f;
+      s_del[row] = -d;                          // the INITIAL ACCUMULATOR of the dP product: the MFMA chain ends in dP - delta
+      // lse + 3: probabilities come out pre-multiplied by scale = 2^-3 (exact in binary floating point), so that
+      // dS = (P scale) (dP - delta) is ONE multiply per score; dV, which sums P scale, is multiplied by 8 at the store (exact)
+      s_lse[row] = row < a.T ? a.lse2[((size_t)b * a.H + h) * a.T + row] + 3.f : 3.f;
     }
   }
   __syncthreads();
   const float c2 = a.scale * LOG2E;
+  // Tried on top of this and dropped (no gain, 56-58 us either way): K / V tiles requested in front of pass 1 and written to LDS
+  // behind it (their HBM latency under pass 1's compute), and the column fragments of step C requested in front of step B.
+  // Round 3 (late): both passes are SOFTWARE-PIPELINED inside the wave and their vector work is cut to the minimum.  The counters
+  // (profiles/r03_pmc_sq.json) showed the kernel as the SUM of its vector time (2 220 vector instructions per wave, 224 of them
+  // quarter-rate exponentials: ~29 us over the three workgroup rounds) and its matrix time (392 MFMAs per wave: ~16 us), with
+  // only 28 % of the matrix cycles overlapped.  Now
+  //   * step A of block i+1 (the S and dP products: 16 MFMAs) is issued BEFORE the vector step B of block i (exp2 and dS of 16
+  //     scores per lane) and the products C of block i (dV, dK / dQ), so every iteration holds matrix work that does not depend
+  //     on its vector work;
+  //   * per score the vector work is one FMA, one exp2 and one multiply: the key masks are gone (padded K / V / Q / dO rows are
+  //     ZERO in LDS, so whatever a padded score is, its products are exact zeros or land in dK / dV rows that are never stored),
+  //     `- delta` is the initial accumulator of the dP chain, and the factor `scale` rides on the probability (exact power of two).
+  static_assert(HD == 64, "scale = 2^-3 is folded into the exponent offset");
 
   // ---------------- pass 1: dK, dV for keys [32w, 32w+32) ----------------
-  {
+  if (!(a.dbg & 1)) {                            // (developer knob rovit_set_attn_debug: timing ablations)
     bf16x8 kf[2][2], vf[2][2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -225,33 +240,42 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const AttnArgs a) {
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) { dv[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    bool kvalid[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) kvalid[kt] = (32 * w + 16 * kt + l15) < a.T;
-
-    for (int qb = 0; qb < 7; ++qb) {
-      f32x4 p[2][2], ds[2][2];     // [qt][kt]: rows q = 32qb + 16qt + 4lg + r, col key = 32w + 16kt + l15
+    f32x4 sb[2][2][2], dpb[2][2][2];      // [buffer][qt][kt]: rows q = 32qb + 16qt + 4lg + r, col key = 32w + 16kt + l15
+    auto stepA = [&](int qb, f32x4 (&s)[2][2], f32x4 (&dp)[2][2]) {
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
         const int qr = 32 * qb + 16 * qt + l15;
         const bf16x8 q0 = row_frag(Qs, qr, 0, lg), q1 = row_frag(Qs, qr, 1, lg);
         const bf16x8 g0 = row_frag(Gs, qr, 0, lg), g1 = row_frag(Gs, qr, 1, lg);
-        const float4 lse4 = *(const float4*)(s_lse + 32 * qb + 16 * qt + 4 * lg);
         const float4 del4 = *(const float4*)(s_del + 32 * qb + 16 * qt + 4 * lg);
-        const float lse_r[4] = {lse4.x, lse4.y, lse4.z, lse4.w};
-        const float del_r[4] = {del4.x, del4.y, del4.z, del4.w};
+        const f32x4 nd = {del4.x, del4.y, del4.z, del4.w};
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-          f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          s = mfma16(q0, kf[kt][0], s);  s = mfma16(q1, kf[kt][1], s);
-          dp = mfma16(g0, vf[kt][0], dp); dp = mfma16(g1, vf[kt][1], dp);
+          f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          z = mfma16(q0, kf[kt][0], z);
+          s[qt][kt] = mfma16(q1, kf[kt][1], z);
+          f32x4 d = mfma16(g0, vf[kt][0], nd);
+          dp[qt][kt] = mfma16(g1, vf[kt][1], d);
+        }
+      }
+    };
+    stepA(0, sb[0], dpb[0]);
+#pragma unroll
+    for (int qb = 0; qb < 7; ++qb) {
+      if (qb + 1 < 7) stepA(qb + 1, sb[(qb + 1) & 1], dpb[(qb + 1) & 1]);
+      f32x4 p[2][2], ds[2][2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const float4 lse4 = *(const float4*)(s_lse + 32 * qb + 16 * qt + 4 * lg);
+        const float lse_r[4] = {lse4.x, lse4.y, lse4.z, lse4.w};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pr = kvalid[kt] ? __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse_r[r])) : 0.f;
+            const float pr = __builtin_amdgcn_exp2f(fmaf(sb[qb & 1][qt][kt][r], c2, -lse_r[r]));     // P scale
             p[qt][kt][r] = pr;
-            ds[qt][kt][r] = pr * fmaf(dp[r], a.scale, -del_r[r]);
+            ds[qt][kt][r] = pr * dpb[qb & 1][qt][kt][r];
           }
-        }
       }
       bf16x8 pf[2], dsf[2];
 #pragma unroll
@@ -262,7 +286,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const AttnArgs a) {
         const bf16x8 qT = col_frag(Qs, 32 * qb, dt, l15, lg);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-          dv[dt][kt] = mfma16(gT, pf[kt], dv[dt][kt]);            // dV^T[d][key]
+          dv[dt][kt] = mfma16(gT, pf[kt], dv[dt][kt]);            // dV^T[d][key] (x scale)
           dk[dt][kt] = mfma16(qT, dsf[kt], dk[dt][kt]);           // dK^T[d][key]
         }
       }
@@ -274,21 +298,26 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const AttnArgs a) {
         bf16* dst = a.dqkv + ((size_t)b * a.T + key) * ld + h * HD + 4 * lg;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
+          f32x4 v = dv[dt][kt];
+          v[0] *= 8.f; v[1] *= 8.f; v[2] *= 8.f; v[3] *= 8.f;
           *(bf16x4*)(dst + a.H * HD + 16 * dt) = pack4(dk[dt][kt]);
-          *(bf16x4*)(dst + 2 * a.H * HD + 16 * dt) = pack4(dv[dt][kt]);
+          *(bf16x4*)(dst + 2 * a.H * HD + 16 * dt) = pack4(v);
         }
       }
     }
   }
 
   // ---------------- pass 2: dQ for queries [32w, 32w+32) ----------------
-  {
+  if (!(a.dbg & 2)) {
     bf16x8 qf[2][2], gf[2][2];
-    float lq[2], dq_[2];
+    float lq[2];
+    f32x4 ndq[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       const int qr = 32 * w + 16 * qt + l15;
-      lq[qt] = s_lse[qr]; dq_[qt] = s_del[qr];
+      lq[qt] = s_lse[qr];
+      const float nd = s_del[qr];
+      ndq[qt] = (f32x4){nd, nd, nd, nd};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) { qf[qt][ks] = row_frag(Qs, qr, ks, lg); gf[qt][ks] = row_frag(Gs, qr, ks, lg); }
     }
@@ -297,8 +326,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const AttnArgs a) {
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) dq[dt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int kb = 0; kb < 7; ++kb) {
-      f32x4 ds[2][2];             // [kt][qt]: rows key = 32kb + 16kt + 4lg + r, col q = 32w + 16qt + l15
+    f32x4 sb[2][2][2], dpb[2][2][2];      // [buffer][kt][qt]: rows key = 32kb + 16kt + 4lg + r, col q = 32w + 16qt + l15
+    auto stepA = [&](int kb, f32x4 (&s)[2][2], f32x4 (&dp)[2][2]) {
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
         const int kr = 32 * kb + 16 * kt + l15;
@@ -306,17 +335,26 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const AttnArgs a) {
         const bf16x8 v0 = row_frag(Vs, kr, 0, lg), v1 = row_frag(Vs, kr, 1, lg);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-          f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          s = mfma16(k0, qf[qt][0], s);  s = mfma16(k1, qf[qt][1], s);
-          dp = mfma16(v0, gf[qt][0], dp); dp = mfma16(v1, gf[qt][1], dp);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = 32 * kb + 16 * kt + 4 * lg + r;
-            const float pr = key < a.T ? __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lq[qt])) : 0.f;
-            ds[kt][qt][r] = pr * fmaf(dp[r], a.scale, -dq_[qt]);
-          }
+          f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          z = mfma16(k0, qf[qt][0], z);
+          s[kt][qt] = mfma16(k1, qf[qt][1], z);
+          f32x4 d = mfma16(v0, gf[qt][0], ndq[qt]);
+          dp[kt][qt] = mfma16(v1, gf[qt][1], d);
         }
       }
+    };
+    stepA(0, sb[0], dpb[0]);
+#pragma unroll
+    for (int kb = 0; kb < 7; ++kb) {
+      if (kb + 1 < 7) stepA(kb + 1, sb[(kb + 1) & 1], dpb[(kb + 1) & 1]);
+      f32x4 ds[2][2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            ds[kt][qt][r] = __builtin_amdgcn_exp2f(fmaf(sb[kb & 1][kt][qt][r], c2, -lq[qt])) * dpb[kb & 1][kt][qt][r];
       bf16x8 dsf[2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) dsf[qt] = pack8(ds[0][qt], ds[1][qt]);

@@ -232,10 +232,12 @@ def test_fused_mlp_backward_is_run_to_run_identical_at_full_size():
 
 
 @pytest.mark.parametrize('B,Tk', [(1, 197), (2, 197), (5, 197), (3, 64), (2, 208), (4, 33), (7, 1), (260, 197)])
-def test_pipelined_attention_backward_is_bit_identical_to_the_staged_kernel(B, Tk):
-    """attn_bwd_pipe_kernel (persistent workgroups, tiles by LDS-DMA while the previous pass computes, padded rows masked through
-    lse = +inf instead of zero-filled tiles) runs the same two passes in the same order as attn_bwd_kernel: dQ, dK, dV must be
-    bit-identical, for ragged token counts, batches smaller and larger than the persistent grid, and over repeated launches."""
+def test_persistent_attention_backward_agrees_with_the_staged_kernel(B, Tk):
+    """attn_bwd_pipe_kernel (opt-in: persistent workgroups, tiles by LDS-DMA while the previous pass computes, padded rows masked
+    through lse = +inf instead of zero-filled tiles) runs the same two passes as attn_bwd_kernel.  Until the staged kernel folded
+    `- delta` into the dP accumulator and `scale` into the probability (late round 3) the two were bit-identical; now they agree
+    to fp32 rounding in front of the bf16 conversion of dS, i.e. to an occasional neighbouring bf16 value.  Ragged token counts,
+    batches smaller and larger than the persistent grid; each kernel bit-identical run to run."""
     native = _native()
     H = 3
     torch.manual_seed(B * 1000 + Tk)
@@ -255,8 +257,10 @@ def test_pipelined_attention_backward_is_bit_identical_to_the_staged_kernel(B, T
             assert torch.equal(outs[pipe].view(torch.int16), dqkv.view(torch.int16))       # run to run
         outs[pipe] = dqkv
     native.call('rovit_set_attn_bwd_pipe', 0)      # the library default
-    assert torch.isfinite(outs[1].float()).all()
-    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    assert torch.isfinite(outs[1].float()).all() and torch.isfinite(outs[0].float()).all()
+    d = (outs[0].float() - outs[1].float()).abs()
+    scale = float(outs[1].float().abs().max())
+    assert float(d.max()) <= 2 ** -6 * scale and float(d.mean()) <= 2e-4 * scale, (float(d.max()), float(d.mean()), scale)
 
 
 @pytest.mark.parametrize('layers,G,B', [([192, 64, 16, 1], 5, 256), ([192, 64, 16, 1], 32, 512), ([16, 8, 1], 5, 33), ([192, 64, 16, 1], 5, 1),

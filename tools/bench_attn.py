@@ -62,6 +62,10 @@ def main():
         res[name] = round(timed(bwd), 2)
     lib.rovit_set_attn_debug(0)
     lib.rovit_set_attn_bwd_pipe(0)
+    for bits, name in ((1, 'staged_no_pass1'), (2, 'staged_no_pass2'), (3, 'staged_no_passes')):      # the default kernel's own ablations
+        lib.rovit_set_attn_debug(bits)
+        res[name] = round(timed(bwd), 2)
+    lib.rovit_set_attn_debug(0)
     print(json.dumps(res))
 
 

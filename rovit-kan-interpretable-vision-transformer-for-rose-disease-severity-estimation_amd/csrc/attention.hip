@@ -211,8 +211,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const AttnArgs a) {
   }
   __syncthreads();
   const float c2 = a.scale * LOG2E;
-  // Tried on top of this and dropped (no gain, 56-58 us either way): K / V tiles requested in front of pass 1 and written to LDS
-  // behind it (their HBM latency under pass 1's compute), and the column fragments of step C requested in front of step B.
+  // Where the 56-58 us go (ablations with rovit_set_attn_debug, tools/bench_attn.py; three workgroup rounds per launch): tile
+  // staging + statistics 19 us -- each round's 256 workgroups pull their 150 KB at the ~24 GB/s a CU gets on HBM misses, which
+  // is also ~6 TB/s chip-wide --, pass 1 25 us (of it: S / dP products and the vector step 6, the dV / dK products with their
+  // transposed operand reads 10, the dK / dV stores 6: all CUs store at once, 12.7 MB per round at the HBM write rate), pass 2
+  // 13 us.  Load, compute and store bursts of the whole chip are in phase, so HBM idles while the passes run.  Tried on top of
+  // this and dropped (no gain, 56-60 us): K / V tiles requested in front of pass 1 and written to LDS behind it; the column
+  // fragments of step C requested in front of step B; dK / dV / dQ leaving through a wave-private LDS patch as whole 128-byte rows.
   // Round 3 (late): both passes are SOFTWARE-PIPELINED inside the wave and their vector work is cut to the minimum.  The counters
   // (profiles/r03_pmc_sq.json) showed the kernel as the SUM of its vector time (2 220 vector instructions per wave, 224 of them
   // quarter-rate exponentials: ~29 us over the three workgroup rounds) and its matrix time (392 MFMAs per wave: ~16 us), with

@@ -191,10 +191,10 @@ def mlp_roofline(dev):
     dXb = torch.empty(M, 192, device=dev, dtype=bf)
     wbytes = 2.0 * 2 * 768 * 192
     res = {}
-    res['fused_fwd_train'] = _entry(dev, lambda: lib.rovit_mlp_fused_fwd(p(xhat2), p(ws), p(b1), p(b2), p(act), p(dact), p(X), p(xhat), p(rstd), 1e-6, M, sp),
+    res['fused_fwd_train'] = _entry(dev, lambda: lib.rovit_mlp_fused_fwd(p(xhat2), p(ws), p(b1), p(b2), p(act), p(dact), p(X), p(xhat), p(rstd), 1e-6, M, M, sp),
                                     2.0 * M * 192 * 2 + 2.0 * M * 768 * 2 + 8.0 * M * 192 + 4.0 * M + wbytes, 4.0 * M * 768 * 192,
                                     'mlp_fused_kernel<0,2,8,false,true> (in-wave pipeline, GELU table): fc1 + GELU + fc2 + residual + LayerNorm, act and gelu\' kept, M=50432', 'mlp_fused_fwd_train')
-    res['fused_fwd_inference'] = _entry(dev, lambda: lib.rovit_mlp_fused_fwd(p(xhat2), p(ws), p(b1), p(b2), None, None, p(X), p(xhat), p(rstd), 1e-6, M, sp),
+    res['fused_fwd_inference'] = _entry(dev, lambda: lib.rovit_mlp_fused_fwd(p(xhat2), p(ws), p(b1), p(b2), None, None, p(X), p(xhat), p(rstd), 1e-6, M, M, sp),
                                         2.0 * M * 192 * 2 + 8.0 * M * 192 + 4.0 * M + wbytes, 4.0 * M * 768 * 192,
                                         'mlp_fused_kernel<0,0,8,false,true>: the same, nothing kept (inference)', 'mlp_fused_fwd_inference')
     dact.uniform_(0, 1)
@@ -220,9 +220,11 @@ def wgrad_roofline(dev, iters=30):
     arr = lambda xs: (C.c_int * len(xs))(*xs)
     a_dy, a_a, a_ws = native.ptr_array(dY), native.ptr_array(A), native.ptr_array(ws)
     ldy, lda, Ns, Ks = arr([n for n, _ in shapes]), arr([k for _, k in shapes]), arr([n for n, _ in shapes]), arr([k for _, k in shapes])
+    # the step's operand layouts: act (A of fc2) and dpre (dY of fc1) are chunk-major, written so by the one-launch MLP kernels
+    a_blk, y_blk = arr([0, 1, 0, 0]), arr([0, 0, 1, 0])
 
     def run():
-        native.call('rovit_wgrad_multi', a_dy, ldy, a_a, lda, Ns, Ks, a_ws, 4, M, splits, native.stream_ptr())
+        native.call('rovit_wgrad_multi_ex', a_dy, ldy, a_a, lda, Ns, Ks, a_ws, a_blk, y_blk, 4, M, splits, native.stream_ptr())
     _warm_clocks(dev)
     ms = _event_avg_ms(dev, run, iters)
     ms_train = _event_avg_ms(dev, run, iters, per_launch=False)

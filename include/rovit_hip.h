@@ -150,7 +150,8 @@ int rovit_vit_forward_f32(const float* images, const float* const* params, void*
  * explainability taps read (reference explainability/gradcam.py:18-60 hooks blocks[-1].norm1 for activations and
  * gradients; attention_maps.py:24-32 hooks blocks[i].attn): the fused kernels' own buffers, no extra copy.
  *   XHAT1 / XHAT2: bf16 (M,192) normalised rows before the norm1 / norm2 affine; RSTD1 / RSTD2: fp32 (M)
- *   QKV: bf16 (M,576); ATTN_O: bf16 (M,192) attention output before proj; ACT: bf16 (M,768) gelu(fc1)
+ *   QKV: bf16 (M,576); ATTN_O: bf16 (M,192) attention output before proj; ACT: bf16 gelu(fc1), (M,768) row-major when the
+ *   two-launch MLP half ran (batches below rovit_set_mlp_fused_min_rows), CHUNK-MAJOR [24][M][32] when the one-launch half did
  *   DQKV: bf16 (M,576) gradient w.r.t. the qkv output of `block`, valid after rovit_vit_backward has processed that
  *   block and before it processes block-2 (call it with first_block = last_block = block, then read) */
 enum { ROVIT_WS_XHAT1 = 0, ROVIT_WS_RSTD1 = 1, ROVIT_WS_QKV = 2, ROVIT_WS_ATTN_O = 3, ROVIT_WS_XHAT2 = 4, ROVIT_WS_RSTD2 = 5,
@@ -187,15 +188,20 @@ int rovit_gemm_resid_ln(const void* A, int lda, const void* W, int ldw, int M, i
  * the backward needs) may both be NULL (inference: nothing is kept), or dact alone.  `wstream` is the weight image written
  * by rovit_mlp_prepare_stream (rovit_mlp_stream_bytes() bytes) from w1f = the bf16 fc1 weight with the norm2 affine folded in
  * (rovit_prep_weight's Wf, (768,192)) and w2 = the bf16 fc2 weight (192,768); b1 = the folded fc1 bias (768), b2 (192).
- * act and dact are bit-identical to rovit_gemm_nt(ROVIT_EPI_GELU)'s outputs. */
+ * The VALUES of act and dact are bit-identical to rovit_gemm_nt(ROVIT_EPI_GELU)'s outputs; their LAYOUT is chunk-major: element
+ * (row m, hidden unit h) of a tensor of act_rows rows at ((h / 32) * act_rows + m) * 32 + h % 32, so that a 16-row tile's store is one
+ * contiguous kilobyte (row-major the launch took 94 us once its 155 MB of outputs no longer fit the Infinity Cache, chunk-major 76).
+ * A launch may cover a row range of the tensors: pass act / dact advanced by first_row * 32 elements, M = rows of the range,
+ * act_rows = rows of the whole tensors (= M for a whole-batch call). */
 size_t rovit_mlp_stream_bytes(void);
 int rovit_mlp_prepare_stream(const void* w1f, const void* w2, void* wstream, rovit_stream_t stream);
 int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const float* b1, const float* b2, void* act, void* dact, float* X,
-                        void* xhat_out, float* rstd_out, float eps, int M, rovit_stream_t stream);
+                        void* xhat_out, float* rstd_out, float eps, int M, int act_rows, rovit_stream_t stream);
 /* The dgrad chain of the same half in ONE launch (autograd of the above, training/trainer.py:119,136):
  *   dpre (M,768) = (dY (M,192) W2T^T) * dact        -- kept: the fc1 weight gradient reads it (bit-identical to rovit_gemm_nt(ROVIT_EPI_MUL))
  *   dX (M,192) += rstd2 (g - mean(g) - xhat2 mean(g xhat2)),  g = dpre W1T^T;   dXb = bf16(dX)     (= rovit_gemm_ln_bwd)
- * wstream_bwd: rovit_mlp_prepare_stream(w1f := W2T bf16 (768,192), w2 := W1T bf16 (192,768), norm2 affine folded in). */
+ * wstream_bwd: rovit_mlp_prepare_stream(w1f := W2T bf16 (768,192), w2 := W1T bf16 (192,768), norm2 affine folded in).
+ * dact (input) and dpre (output) are chunk-major [24][M][32] like the forward's act / dact; rovit_wgrad_multi_ex reads them as such. */
 int rovit_mlp_fused_bwd(const void* dY, const void* wstream_bwd, const void* dact, void* dpre, const void* xhat2, const float* rstd2,
                         float* dX, void* dXb, int M, rovit_stream_t stream);
 /* developer knob (timing ablations of the lockstep fused MLP kernels: bit 0 skip the row-wise epilogue, 1 skip GELU, 2 skip fc2, 3 skip fc1; results are then wrong) */
@@ -232,6 +238,10 @@ int rovit_wgrad(const void* dY, int ldy, const void* A, int lda, int M, int N, i
  * rovit_wgrad_workspace_bytes(N[j], K[j], splits) and finished by rovit_wgrad_reduce with the same `splits`. */
 int rovit_wgrad_multi(const void* const* dY, const int* ldy, const void* const* A, const int* lda, const int* N, const int* K,
                       float* const* ws, int n, int M, int splits, rovit_stream_t stream);
+/* the same with per-problem operand layouts: a_blk[j] / y_blk[j] != 0 = A / dY of problem j is chunk-major [cols / 32][M][32]
+ * (rovit_mlp_fused_fwd's act, rovit_mlp_fused_bwd's dpre); NULL = all row-major */
+int rovit_wgrad_multi_ex(const void* const* dY, const int* ldy, const void* const* A, const int* lda, const int* N, const int* K,
+                         float* const* ws, const int* a_blk, const int* y_blk, int n, int M, int splits, rovit_stream_t stream);
 int rovit_wgrad_reduce(const float* ws, int splits, int N, int K, const float* gamma, const float* beta, const float* W,
                        float* dW, float* db, float* dgamma, float* dbeta, float* g_scratch, rovit_stream_t stream);
 /* softmax(q k^T * scale) v per (image, head); qkv bf16 (B*T, 3*H*64) = [q|k|v]; out bf16 (B*T, H*64);

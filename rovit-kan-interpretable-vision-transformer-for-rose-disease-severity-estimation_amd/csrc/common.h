@@ -171,7 +171,7 @@ int rovit_layernorm_bwd_rows(const void* dxhat, const void* xhat, const float* r
                              rovit_stream_t stream);
 
 // several weight gradients G[N][K] = dY[M][N]^T A[M][K] that share M, in one launch (gemm.hip)
-struct RovitWgradDesc { const void* dY; int ldy; const void* A; int lda; int N, K; float* ws; };
+struct RovitWgradDesc { const void* dY; int ldy; const void* A; int lda; int N, K; float* ws; int a_blk, y_blk; };   // *_blk: operand chunk-major [cols/32][M][32]
 int rovit_wgrad_batch(const RovitWgradDesc* descs, int n, int M, int splits, rovit_stream_t stream);
 
 struct RovitReduceDesc {

@@ -1183,6 +1183,7 @@ struct WgradProb {
   float* slab;          // [splits][N][K]
   float* colsum;        // [splits][N]
   int k_tiles, tile0;   // tiles of this problem are [tile0, tile0 + n_tiles * k_tiles) of a split's tile list
+  int a_blk, y_blk;     // operand stored CHUNK-MAJOR [cols / 32][M][32] (the one-launch MLP half's act / dpre, mlp_fused.hip) instead of row-major
 };
 constexpr int WG_MAXPROB = 4;
 struct WgradArgs {
@@ -1241,11 +1242,19 @@ __global__ __launch_bounds__(128 * WN) void wgrad_kernel(const WgradArgs g) {
 #pragma unroll
   for (int i = 0; i < CHY; ++i) {
     const int c = tid + i * NT;
-    y_row[i] = c / CPRY;
-    const int col = (c - y_row[i] * CPRY) * 8;
+    int col;
+    if (pr.y_blk) {       // chunk-major: four lanes read the 64 contiguous bytes of a row, consecutive rows are adjacent (a wave reads 1 KB runs)
+      y_row[i] = (c >> 2) % WG_MSTEP;
+      col = ((c >> 2) / WG_MSTEP) * 32 + (c & 3) * 8;
+      ybase[i] = pr.dY + (size_t)((n0 + col) >> 5) * g.M * 32 + ((n0 + col) & 31);
+    } else {
+      y_row[i] = c / CPRY;
+      col = (c - y_row[i] * CPRY) * 8;
+      ybase[i] = pr.dY + n0 + col;
+    }
     y_lds[i] = y_row[i] * SY + col;
-    ybase[i] = pr.dY + n0 + col;
   }
+  const int ldy_eff = pr.y_blk ? 32 : pr.ldy, lda_eff = pr.a_blk ? 32 : pr.lda;
 #pragma unroll
   for (int i = 0; i < CHA; ++i) {
     const int c = tid + i * NT;
@@ -1254,13 +1263,16 @@ __global__ __launch_bounds__(128 * WN) void wgrad_kernel(const WgradArgs g) {
       const int rest = c >> 6, row_hi = rest / (CPRA / 2), pair = rest - row_hi * (CPRA / 2);
       a_row[i] = (c & 31) + 32 * row_hi;
       col = (pair * 2 + ((c >> 5) & 1)) * 8;
+    } else if (pr.a_blk) {
+      a_row[i] = (c >> 2) % WG_MSTEP;
+      col = ((c >> 2) / WG_MSTEP) * 32 + (c & 3) * 8;
     } else {
       a_row[i] = c / CPRA;
       col = (c - a_row[i] * CPRA) * 8;
     }
     a_lds[i] = a_row[i] * SA + col;
     a_col[i] = k0 + col;
-    abase[i] = pr.A + k0 + col;
+    abase[i] = pr.a_blk ? pr.A + (size_t)((k0 + col) >> 5) * g.M * 32 + ((k0 + col) & 31) : pr.A + k0 + col;
   }
   const int m_last = g.M - 1;
   auto load = [&](int mbase, bf16x8* ry, RA* ra) {
@@ -1269,14 +1281,14 @@ __global__ __launch_bounds__(128 * WN) void wgrad_kernel(const WgradArgs g) {
       int m = mbase + y_row[i];
       m = m < m_last ? m : m_last;                      // clamp (never branch around a load); tail rows are zeroed in store()
       const int yr = PATCH ? m + m / (g.patch_tokens - 1) + 1 : m;
-      ry[i] = *(const bf16x8*)(ybase[i] + (size_t)yr * pr.ldy);
+      ry[i] = *(const bf16x8*)(ybase[i] + (size_t)yr * ldy_eff);
     }
 #pragma unroll
     for (int i = 0; i < CHA; ++i) {
       int m = mbase + a_row[i];
       m = m < m_last ? m : m_last;
       if constexpr (IMG) ra[i] = load_f8(patch_src(g.img, m, a_col[i]));
-      else ra[i] = *(const bf16x8*)(abase[i] + (size_t)m * pr.lda);
+      else ra[i] = *(const bf16x8*)(abase[i] + (size_t)m * lda_eff);
     }
   };
   auto tobf = [&](const RA& v) -> bf16x8 {
@@ -1661,7 +1673,8 @@ int rovit_wgrad_batch(const RovitWgradDesc* descs, int n, int M, int splits, rov
     ROVIT_CHECK_ARG(d.dY && d.A && d.ws, ROVIT_ERR_NULL, "wgrad_batch: null pointer");
     ROVIT_CHECK_ARG(d.N % 96 == 0 && d.K % 192 == 0, ROVIT_ERR_SHAPE, "wgrad_batch: unsupported shape N=%d K=%d", d.N, d.K);
     ROVIT_CHECK_ARG(d.ldy % 8 == 0 && d.lda % 8 == 0 && rovit_aligned16(d.dY) && rovit_aligned16(d.A), ROVIT_ERR_ALIGN, "wgrad_batch: alignment");
-    g.p[j] = WgradProb{(const bf16*)d.dY, d.ldy, (const bf16*)d.A, d.lda, d.N, d.K, d.ws, d.ws + (size_t)splits * d.N * d.K, 0, 0};
+    ROVIT_CHECK_ARG(!(d.a_blk && d.K % 32) && !(d.y_blk && d.N % 32), ROVIT_ERR_SHAPE, "wgrad_batch: chunk-major operands need 32-column chunks");
+    g.p[j] = WgradProb{(const bf16*)d.dY, d.ldy, (const bf16*)d.A, d.lda, d.N, d.K, d.ws, d.ws + (size_t)splits * d.N * d.K, 0, 0, d.a_blk, d.y_blk};
   }
   g.M = M;
   g.splits = splits;
@@ -1695,6 +1708,16 @@ extern "C" int rovit_wgrad_multi(const void* const* dY, const int* ldy, const vo
   ROVIT_CHECK_ARG(dY && ldy && A && lda && N && K && ws && n >= 1 && n <= WG_MAXPROB, ROVIT_ERR_NULL, "wgrad_multi: bad arguments");
   RovitWgradDesc d[WG_MAXPROB];
   for (int j = 0; j < n; ++j) d[j] = {dY[j], ldy[j], A[j], lda[j], N[j], K[j], ws[j]};
+  return rovit_wgrad_batch(d, n, M, splits, stream);
+}
+
+// rovit_wgrad_multi with per-problem operand layouts: a_blk[j] / y_blk[j] != 0 = A / dY of problem j is stored chunk-major
+// [cols / 32][M][32] (what rovit_mlp_fused_fwd / _bwd write: act and dpre); NULL arrays = all row-major
+extern "C" int rovit_wgrad_multi_ex(const void* const* dY, const int* ldy, const void* const* A, const int* lda, const int* N, const int* K,
+                                    float* const* ws, const int* a_blk, const int* y_blk, int n, int M, int splits, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(dY && ldy && A && lda && N && K && ws && n >= 1 && n <= WG_MAXPROB, ROVIT_ERR_NULL, "wgrad_multi_ex: bad arguments");
+  RovitWgradDesc d[WG_MAXPROB];
+  for (int j = 0; j < n; ++j) d[j] = {dY[j], ldy[j], A[j], lda[j], N[j], K[j], ws[j], a_blk ? a_blk[j] : 0, y_blk ? y_blk[j] : 0};
   return rovit_wgrad_batch(d, n, M, splits, stream);
 }
 

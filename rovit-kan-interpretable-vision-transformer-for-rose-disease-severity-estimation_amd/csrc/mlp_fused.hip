@@ -80,9 +80,10 @@ struct MlpArgs {
   const bf16* wstream;    // rovit_mlp_prepare_stream image: forward (W1 folded, W2), backward (W2T, W1T folded)
   const float* b1;        // forward: (768) folded fc1 bias
   const float* b2;        // forward: (192) fc2 bias
-  bf16* act;              // forward (M,768) gelu(pre) (MODE >= 1); backward (M,768) dpre (output)
-  bf16* dact;             // forward (M,768) gelu'(pre) (MODE == 2)
-  const bf16* mul;        // backward (M,768) gelu'(pre)
+  bf16* act;              // forward gelu(pre) (MODE >= 1); backward dpre (output).  CHUNK-MAJOR [24][rows][32], see the kernel
+  bf16* dact;             // forward gelu'(pre) (MODE == 2), chunk-major
+  const bf16* mul;        // backward gelu'(pre), chunk-major [24][M][32]
+  int act_rows;           // forward: rows of the whole chunk-major tensors (>= M: a launch may cover a row range of them)
   const bf16* gelu_table; // pipelined forward: the 32 KB table behind the two stream images
   float* X;               // (M,192) forward: residual stream; backward: dX; updated in place
   bf16* xhat;             // forward: next LayerNorm output or NULL; backward: xhat2 (input)
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
     if (KIND) {        // this wave's own gelu' pieces: lane (row l15, q = lg) <- gelu'[row][32 chunk + 8 q .. +7]
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.mul + (size_t)mcl[i] * HID + chunk * HC + lg * 8),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.mul + ((size_t)chunk * g.M + mcl[i]) * HC + lg * 8),
                                          (__attribute__((address_space(3))) void*)(lds + slot * SLOT + (CH_PIECES + w + NW * i) * PIECE), 16, 0, 0);
     }
   };
@@ -177,11 +178,18 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
     for (int ks = 0; ks < 6; ++ks) xf[i][ks] = *(const bf16x8*)(g.xin + (size_t)mcl[i] * D + ks * 32 + lg * 8);
   // buffer resources for the kept activations: rows >= M fall outside num_records and are dropped by the hardware
   __amdgpu_buffer_rsrc_t r_act, r_dact;
-  if (MODE >= 1) r_act = __builtin_amdgcn_make_buffer_rsrc((void*)g.act, 0, (int)((size_t)g.M * HID * 2), 0x00020000);
-  if (MODE == 2) r_dact = __builtin_amdgcn_make_buffer_rsrc((void*)g.dact, 0, (int)((size_t)g.M * HID * 2), 0x00020000);
+  // The kept activations are CHUNK-MAJOR, [24][rows][32] (32 hidden units = 64 bytes per row and chunk): the store instruction of a
+  // 16-row tile then writes ONE contiguous kilobyte instead of 16 pieces of 64 bytes 1 536 bytes apart.  Row-major, the launch
+  // took 94 us once the outputs no longer fit the 256 MB Infinity Cache (as in the training step) against 71 us in a loop over
+  // one buffer set; chunk-major 76 against 69 us (profiles/r03_mlp_store_layout.json: a timing hack that preceded this layout).
+  // cblk = bytes from one chunk to the next; rows beyond M get an offset that stays outside num_records for every chunk.
+  const unsigned cblk = (unsigned)(KIND ? g.M : g.act_rows) * (HC * 2);
+  const int nrec = (int)((size_t)(NCHUNK - 1) * cblk + (size_t)g.M * (HC * 2));
+  if (MODE >= 1) r_act = __builtin_amdgcn_make_buffer_rsrc((void*)g.act, 0, nrec, 0x00020000);
+  if (MODE == 2) r_dact = __builtin_amdgcn_make_buffer_rsrc((void*)g.dact, 0, nrec, 0x00020000);
   unsigned soff[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) soff[i] = (unsigned)mrow[i] * (HID * 2) + lg * 16;
+  for (int i = 0; i < 2; ++i) soff[i] = mrow[i] < g.M ? (unsigned)mrow[i] * (HC * 2) + lg * 16 : 0xF0000000u;
 
   f32x4 a2[12][2];
 #pragma unroll
@@ -225,8 +233,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
       }
     };
     auto store_tile = [&](int i, int c, const bf16x8& av, const bf16x8& dv) {
-      if (MODE >= 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, av), r_act, soff[i] + c * (HC * 2), 0, 0);
-      if (MODE == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dv), r_dact, soff[i] + c * (HC * 2), 0, 0);
+      if (MODE >= 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, av), r_act, soff[i] + c * cblk, 0, 0);
+      if (MODE == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dv), r_dact, soff[i] + c * cblk, 0, 0);
     };
     auto fc2 = [&](const bf16* sb, const bf16x8& av0, const bf16x8& av1) {
 #pragma unroll
@@ -403,7 +411,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
         const bool real = j >= 1 && j <= NCHUNK;                // no such chunk: an offset beyond num_records (no wrap-around: absolute)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const unsigned off = real ? soff[i] + (unsigned)(j - 1) * (HC * 2) : 0xFFFFFF00u;
+          const unsigned off = real ? soff[i] + (unsigned)(j - 1) * cblk : 0xFFFFFF00u;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, av[i]), r_act, off, 0, 0);
           if (MODE == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dv[i]), r_dact, off, 0, 0);
         }
@@ -488,8 +496,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
     if (MODE >= 1) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, av[i]), r_act, soff[i] + c * (HC * 2), 0, 0);
-        if (MODE == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dv[i]), r_dact, soff[i] + c * (HC * 2), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, av[i]), r_act, soff[i] + c * cblk, 0, 0);
+        if (MODE == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dv[i]), r_dact, soff[i] + c * cblk, 0, 0);
       }
     }
     // ---- second GEMM: out^T[192][32 rows] += W[:, chunk] act^T ----
@@ -742,10 +750,13 @@ extern "C" int rovit_mlp_prepare_stream(const void* w1f, const void* w2, void* w
 
 // X(M,192) += fc2(GELU(fc1(xhat2))) and the LayerNorm behind it, one launch.  act / dact: NULL for inference (nothing kept);
 // dact alone may be NULL (gelu' recomputed by the backward).  xhat_out NULL: no LayerNorm.
+// act / dact are CHUNK-MAJOR: element (row m, hidden unit h) of a tensor of act_rows rows lives at ((h / 32) * act_rows + m) * 32 + h % 32.
+// A launch may cover a row range of such a tensor: pass the pointers advanced by first_row * 32 elements and act_rows of the whole.
 extern "C" int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const float* b1, const float* b2, void* act, void* dact,
-                                   float* X, void* xhat_out, float* rstd_out, float eps, int M, rovit_stream_t stream) {
+                                   float* X, void* xhat_out, float* rstd_out, float eps, int M, int act_rows, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(xhat2 && wstream && b1 && b2 && X, ROVIT_ERR_NULL, "mlp_fused_fwd: null pointer");
-  ROVIT_CHECK_ARG(M > 0 && (size_t)M * HID * 2 < ((size_t)1 << 31), ROVIT_ERR_SHAPE, "mlp_fused_fwd: M = %d out of range", M);
+  ROVIT_CHECK_ARG(M > 0 && act_rows >= M && (size_t)act_rows * HID * 2 < ((size_t)1 << 31), ROVIT_ERR_SHAPE,
+                  "mlp_fused_fwd: M = %d, act_rows = %d out of range", M, act_rows);
   ROVIT_CHECK_ARG(act || !dact, ROVIT_ERR_NULL, "mlp_fused_fwd: dact without act");
   ROVIT_CHECK_ARG(!xhat_out || rstd_out, ROVIT_ERR_NULL, "mlp_fused_fwd: rstd_out missing");
   ROVIT_CHECK_ARG(rovit_aligned16(xhat2) && rovit_aligned16(wstream) && rovit_aligned16(b1) && rovit_aligned16(b2) && rovit_aligned16(X) &&
@@ -753,7 +764,7 @@ extern "C" int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const
                   ROVIT_ERR_ALIGN, "mlp_fused_fwd: buffers must be 16-byte aligned");
   MlpArgs g{};
   g.xin = (const bf16*)xhat2; g.wstream = (const bf16*)wstream; g.b1 = b1; g.b2 = b2; g.act = (bf16*)act; g.dact = (bf16*)dact;
-  g.X = X; g.xhat = (bf16*)xhat_out; g.rstd = rstd_out; g.eps = eps; g.M = M; g.dbg = g_mlp_dbg;
+  g.X = X; g.xhat = (bf16*)xhat_out; g.rstd = rstd_out; g.eps = eps; g.M = M; g.act_rows = act_rows; g.dbg = g_mlp_dbg;
   hipStream_t st = (hipStream_t)stream;
   const int nw = g_mlp_waves;
   const dim3 grid((M + 32 * nw - 1) / (32 * nw)), block(64 * nw);
@@ -793,6 +804,7 @@ extern "C" int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const
   return ROVIT_OK;
 }
 
+// (dact and dpre are chunk-major [24][M][32], like the forward's act / dact with act_rows = M.)
 // The dgrad chain of the MLP half in one launch: dpre (M,768) = (dY W2T^T) * dact, kept for the fc1 weight gradient;
 // dX (M,192) += LayerNorm-2-backward(dpre W1T^T) with xhat2 / rstd2 of the forward; dXb = bf16(dX).  wstream_bwd: the image
 // rovit_mlp_prepare_stream builds from (w1f := W2T (768,192), w2 := W1T folded (192,768)).

@@ -41,6 +41,18 @@ inline bool recompute_gelu() {
 // either way; batch 128: 1.33 fused against 1.23 ms, batch 1: 0.99 against 0.66 ms) and for the training step alike.
 int g_mlp_fused_min_rows = [] { const char* e = getenv("ROVIT_MLP_FUSED_MIN_ROWS"); return e ? atoi(e) : 34000; }();
 inline int mlp_fused_min_rows() { return g_mlp_fused_min_rows; }
+// ONE decision for the forward, the dgrad chain and the weight gradients of a training step: the one-launch kernels keep act, gelu'
+// and dpre CHUNK-MAJOR ([24][M][32], mlp_fused.hip), the two-launch kernels row-major, and the weight-gradient launch is told which
+// (RovitWgradDesc::a_blk / y_blk).  Any of the A/B knobs (ROVIT_MLP_FUSED=0, ROVIT_MLP_BWD_FUSED=0, ROVIT_RECOMPUTE_GELU=1,
+// ROVIT_WGRAD_MERGE=0) therefore selects the two-launch path for all three.  The setting must not change between a forward and
+// its backward.
+inline bool mlp_one_launch(long rows) {
+  static const bool on = [] {
+    auto off = [](const char* k) { const char* e = getenv(k); return e && e[0] == '0'; };
+    return !off("ROVIT_MLP_FUSED") && !off("ROVIT_MLP_BWD_FUSED") && !off("ROVIT_WGRAD_MERGE");
+  }();
+  return on && !recompute_gelu() && rows >= mlp_fused_min_rows();
+}
 
 struct Prep {          // byte offsets into the prepared-weight buffer
   size_t wpe;
@@ -341,16 +353,15 @@ int vit_forward_impl(const float* images, const float* const* params, const void
     // inference call keeps neither act nor gelu'.  ROVIT_MLP_FUSED=0: the two-launch path (A/B timing).
     // A fused launch has one workgroup per 256 rows: below ROVIT_MLP_FUSED_MIN_ROWS rows (small batches) it leaves most of the
     // chip idle and the two-launch path, whose grids also split the output columns, is faster.
-    static const bool mlp_fused = !(getenv("ROVIT_MLP_FUSED") && getenv("ROVIT_MLP_FUSED")[0] == '0');
-    if (mlp_fused && !cls_only && batch * T >= mlp_fused_min_rows()) {
+    if (!cls_only && mlp_one_launch((long)batch * T)) {
       char* sn = ws + L.blk0 + (size_t)(i + 1) * L.blk_stride;            // next block's saved-activation area
       EACH_HALF {
         const Half& h = halves[hh];
         float* Xh = X + (size_t)h.b0 * T * D;
+        // act / gelu' chunk-major over the WHOLE batch: this half's rows start 64 bytes x first row into every chunk
         RUN(rovit_mlp_fused_fwd(ROWS(s + L.xhat2, D, 2), q + P.wmlp, (const float*)(q + P.bfc1), bp[B_FC2B],
-                                training ? ROWS(s + L.act, MLP, 2) : nullptr,
-                                (training && !recompute_gelu()) ? ROWS(s + L.dact, MLP, 2) : nullptr, Xh, ROWS(sn + L.xhat1, D, 2),
-                                (float*)ROWS(sn + L.rstd1, 1, 4), eps, h.nb * T, h.st));
+                                training ? ROWS(s + L.act, 32, 2) : nullptr, training ? ROWS(s + L.dact, 32, 2) : nullptr, Xh,
+                                ROWS(sn + L.xhat1, D, 2), (float*)ROWS(sn + L.rstd1, 1, 4), eps, h.nb * T, batch * T, h.st));
       }
       continue;
     }
@@ -499,9 +510,10 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
     RovitWgradDesc wd[4];
     RovitReduceDesc rd[4];
     int n = 0;
-    wd[n] = {xin, D, s + L.act, MLP, D, MLP, (float*)(ws + L.slab_fc2)};
+    const int blk = mlp_one_launch(M) ? 1 : 0;          // act and dpre chunk-major (written by the one-launch MLP kernels)
+    wd[n] = {xin, D, s + L.act, MLP, D, MLP, (float*)(ws + L.slab_fc2), blk, 0};
     rd[n++] = {(const float*)(ws + L.slab_fc2), S_MERGE, D, MLP, nullptr, nullptr, nullptr, bg[B_FC2W], bg[B_FC2B], nullptr, nullptr, nullptr};
-    wd[n] = {dp, MLP, s + L.xhat2, D, MLP, D, (float*)(ws + L.slab_fc1)};
+    wd[n] = {dp, MLP, s + L.xhat2, D, MLP, D, (float*)(ws + L.slab_fc1), 0, blk};
     rd[n++] = {(const float*)(ws + L.slab_fc1), S_MERGE, MLP, D, bp[B_N2W], bp[B_N2B], bp[B_FC1W], bg[B_FC1W], bg[B_FC1B], bg[B_N2W], bg[B_N2B],
                (float*)(ws + L.gscr)};
     wd[n] = {xmid, D, s + L.o, D, D, D, (float*)(ws + L.slab_proj)};
@@ -556,8 +568,7 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
     if (ss && i + 2 < depth && ev_bdone[i + 2] && hipStreamWaitEvent(sA, ev_bdone[i + 2], 0) != hipSuccess) EVFAIL("event wait");
     // A1 + A2 in one launch (mlp_fused.hip): fc2 dgrad x gelu' -> dpre (kept for B2), fc1 dgrad + norm2 backward without
     // re-reading dpre.  ROVIT_MLP_BWD_FUSED=0: the two launches (A/B timing); the gelu'-recompute memory mode keeps them too.
-    static const bool mlp_bwd_fused = !(getenv("ROVIT_MLP_BWD_FUSED") && getenv("ROVIT_MLP_BWD_FUSED")[0] == '0');
-    if (mlp_bwd_fused && !recompute_gelu() && M >= mlp_fused_min_rows()) {
+    if (mlp_one_launch(M)) {
       RUN(rovit_mlp_fused_bwd(xin, q + P.wmlpb, s + L.dact, dp, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmid, M, sA));
     } else {
       if (recompute_gelu())                                                                                            // A1

@@ -35,6 +35,17 @@ def _mlp_problem(M, seed):
     return xhat2, w1, w2, b1, b2, X0
 
 
+def _rows(t, M):
+    """chunk-major [24][M][32] (what the one-launch MLP kernels keep) -> row-major (M,768)"""
+    return t.view(24, M, 32).permute(1, 0, 2).reshape(M, 768).contiguous()
+
+
+def _chunks(t):
+    """row-major (M,768) -> chunk-major [24][M][32], flat"""
+    M = t.shape[0]
+    return t.view(M, 24, 32).permute(1, 0, 2).contiguous().view(M, 768)
+
+
 def _two_launch(native, xhat2, w1, w2, b1, b2, X0, keep=True):
     M = xhat2.shape[0]
     act = torch.empty(M, 768, device=dev(), dtype=torch.bfloat16)
@@ -62,8 +73,9 @@ def _fused(native, xhat2, w1, w2, b1, b2, X0, mode=2, ln=True, waves=None):
     xhat = torch.full((M, 192), float('nan'), device=dev(), dtype=torch.bfloat16) if ln else None
     rstd = torch.full((M,), float('nan'), device=dev()) if ln else None
     native.call('rovit_mlp_fused_fwd', native.ptr(xhat2), native.ptr(ws), native.ptr(b1), native.ptr(b2), native.ptr(act), native.ptr(dact),
-                native.ptr(X), native.ptr(xhat), native.ptr(rstd), 1e-6, M, native.stream_ptr())
-    return act, dact, X, xhat, rstd
+                native.ptr(X), native.ptr(xhat), native.ptr(rstd), 1e-6, M, M, native.stream_ptr())
+    # the kept activations are chunk-major: back to rows for the comparisons (a chunk the kernel failed to write stays NaN)
+    return (_rows(act, M) if act is not None else None), (_rows(dact, M) if dact is not None else None), X, xhat, rstd
 
 
 @pytest.mark.parametrize('waves', [4, 8, 9, 10])   # 8 = lockstep, 9 = waves 4-7 staggered by half a chunk, 10 = in-wave pipeline + GELU table
@@ -130,6 +142,27 @@ def test_pipelined_mlp_half_gelu_table_and_its_fallback_on_special_inputs(M):
     assert float((X1 - Xr).abs().max()) < 2 ** -7 * max(float((X1 - X0).abs().max()), 1.0)
 
 
+def test_fused_mlp_half_on_row_ranges_of_one_chunk_major_tensor():
+    """rovit_vit_forward runs the two half-batches as two launches that write row ranges of ONE chunk-major act / gelu' pair
+    (pointers advanced by first_row x 32 elements, act_rows = rows of the whole): together they must equal one whole-batch launch."""
+    native = _native()
+    M, M0 = 700, 353
+    xhat2, w1, w2, b1, b2, X0 = _mlp_problem(M, 4242)
+    a_ref, d_ref, X_ref, h_ref, r_ref = _fused(native, xhat2, w1, w2, b1, b2, X0)
+    ws = torch.empty(native.load().rovit_mlp_stream_bytes(), dtype=torch.uint8, device=dev())
+    p, sp = native.ptr, native.stream_ptr()
+    native.call('rovit_mlp_prepare_stream', p(w1), p(w2), p(ws), sp)
+    act = torch.full((M, 768), float('nan'), device=dev(), dtype=torch.bfloat16)
+    dact = torch.full((M, 768), float('nan'), device=dev(), dtype=torch.bfloat16)
+    X, xhat, rstd = X0.clone(), torch.empty(M, 192, device=dev(), dtype=torch.bfloat16), torch.empty(M, device=dev())
+    for r0, n in ((0, M0), (M0, M - M0)):
+        native.call('rovit_mlp_fused_fwd', p(xhat2[r0:]), p(ws), p(b1), p(b2), act.data_ptr() + r0 * 64, dact.data_ptr() + r0 * 64,
+                    p(X[r0:]), p(xhat[r0:]), p(rstd[r0:]), 1e-6, n, M, sp)
+    assert torch.equal(_rows(act, M).view(torch.int16), a_ref.view(torch.int16))
+    assert torch.equal(_rows(dact, M).view(torch.int16), d_ref.view(torch.int16))
+    assert torch.equal(X, X_ref) and torch.equal(xhat.view(torch.int16), h_ref.view(torch.int16)) and torch.equal(rstd, r_ref)
+
+
 @pytest.mark.parametrize('M', [300, 197 * 16])
 def test_fused_mlp_half_modes_keep_only_what_is_asked_for(M):
     """Inference keeps neither act nor gelu' (MODE 0), the gelu'-recompute memory mode keeps act alone (MODE 1), no LayerNorm
@@ -193,8 +226,29 @@ def test_fused_mlp_backward_equals_the_two_launch_dgrad_chain_and_a_torch_refere
     dpre1 = torch.full((M, 768), float('nan'), device=dev(), dtype=torch.bfloat16)
     dXb1 = torch.full((M, 192), float('nan'), device=dev(), dtype=torch.bfloat16)
     dX1 = dX0.clone()
-    native.call('rovit_mlp_fused_bwd', p(dY), p(ws), p(dact), p(dpre1), p(xh), p(rstd), p(dX1), p(dXb1), M, sp)
+    dact_c = _chunks(dact)                                             # the one-launch kernels read gelu' and write dpre chunk-major
+    native.call('rovit_mlp_fused_bwd', p(dY), p(ws), p(dact_c), p(dpre1), p(xh), p(rstd), p(dX1), p(dXb1), M, sp)
+    dpre1_c = dpre1
+    dpre1 = _rows(dpre1, M)
     assert torch.equal(dpre0.view(torch.int16), dpre1.view(torch.int16))
+    # the weight-gradient launch reads the chunk-major operands in place (rovit_wgrad_multi_ex): dW1 = dpre^T xhat2 from the
+    # chunk-major dpre (dY operand) and dW2 = dY^T act with a chunk-major A operand must equal the row-major launch bit for bit
+    if M >= 64:
+        import ctypes as C
+        lib = native.load()
+        S = 2
+        arr = lambda xs: (C.c_int * len(xs))(*xs)
+        shapes = [(768, 192), (192, 768)]                              # (N, K): fc1 (dY = dpre, A = xhat2), fc2 (dY = dY, A = "act" := dact)
+        outs = []
+        for blocked in (0, 1):
+            wsl = [torch.zeros(lib.rovit_wgrad_workspace_bytes(n, k, S), dtype=torch.uint8, device=dev()) for n, k in shapes]
+            dys = [dpre1_c if blocked else dpre1, dY]
+            As = [xh, dact_c if blocked else dact]
+            native.call('rovit_wgrad_multi_ex', native.ptr_array(dys), arr([768, 192]), native.ptr_array(As), arr([192, 768]), arr([768, 192]),
+                        arr([192, 768]), native.ptr_array(wsl), arr([0, blocked]), arr([blocked, 0]), 2, M, S, sp)
+            outs.append([w.clone() for w in wsl])
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
     assert torch.equal(dXb1.view(torch.int16), bf(dX1).view(torch.int16))
     gq = bf(dpre1.float() @ w1t.float().t()).float()                  # the second dgrad, rounded as the kernel stages it
     h = xh.float()
@@ -213,7 +267,7 @@ def test_fused_mlp_backward_is_run_to_run_identical_at_full_size():
     g = torch.Generator(device='cpu').manual_seed(4)
     r = lambda *s: torch.randn(*s, generator=g)
     dY, w2t, w1t = bf(r(M, 192)).to(dev()), bf(r(768, 192) * 0.05).to(dev()), bf(r(192, 768) * 0.05).to(dev())
-    dact, xh = bf(torch.rand(M, 768, generator=g)).to(dev()), bf(r(M, 192)).to(dev())
+    dact, xh = bf(torch.rand(M, 768, generator=g)).to(dev()), bf(r(M, 192)).to(dev())      # (read as chunk-major: any values do)
     rstd, dX0 = (torch.rand(M, generator=g) + 0.5).to(dev()), r(M, 192).to(dev())
     p, sp = native.ptr, native.stream_ptr()
     ws = torch.empty(native.load().rovit_mlp_stream_bytes(), dtype=torch.uint8, device=dev())

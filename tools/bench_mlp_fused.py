@@ -37,7 +37,7 @@ def main():
     def fused(mode):
         a = p(act) if mode >= 1 else None
         d = p(dact) if mode == 2 else None
-        return lambda: lib.rovit_mlp_fused_fwd(p(xhat2), p(ws), p(b1), p(b2), a, d, p(X), p(xhat), p(rstd), 1e-6, M, sp)
+        return lambda: lib.rovit_mlp_fused_fwd(p(xhat2), p(ws), p(b1), p(b2), a, d, p(X), p(xhat), p(rstd), 1e-6, M, M, sp)
 
     def with_waves(nw, fn):
         def run():

@@ -25,8 +25,8 @@ def timed(fn, iters=30):
     return round(e0.elapsed_time(e1) / iters * 1e3, 2)
 a = torch.randn(4096, 4096, device=dev, dtype=bf)
 for _ in range(50): a @ a
-train = lambda: lib.rovit_mlp_fused_fwd(p(xhat2), p(ws), p(b1), p(b2), p(act), p(dact), p(X), p(xhat), p(rstd), 1e-6, M, sp)
-infer = lambda: lib.rovit_mlp_fused_fwd(p(xhat2), p(ws), p(b1), p(b2), None, None, p(X), p(xhat), p(rstd), 1e-6, M, sp)
+train = lambda: lib.rovit_mlp_fused_fwd(p(xhat2), p(ws), p(b1), p(b2), p(act), p(dact), p(X), p(xhat), p(rstd), 1e-6, M, M, sp)
+infer = lambda: lib.rovit_mlp_fused_fwd(p(xhat2), p(ws), p(b1), p(b2), None, None, p(X), p(xhat), p(rstd), 1e-6, M, M, sp)
 out = {}
 for wv, tag in ((8, 'lockstep'), (9, 'staggered')):
   lib.rovit_set_mlp_waves(wv)

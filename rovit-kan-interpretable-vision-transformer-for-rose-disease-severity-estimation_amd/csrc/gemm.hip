@@ -1201,6 +1201,21 @@ struct WgradArgs {
 // slabs to write and reduce (slab bytes = splits x N x K x 4), at the price of more operand re-reads through the XCD's
 // L2 (every tile of a split streams the same rows; all tiles of a split run on one XCD).
 // WN = waves along n (2: the four-wave workgroup above; 4: EIGHT waves as 2 (k) x 4 (n) for 192 x 192 tiles, round 3).
+// Staging chunk c (16 bytes) of a step's [WG_MSTEP rows][W columns] operand tile when the operand is stored CHUNK-MAJOR
+// ([cols / 32][M][32]): eight consecutive lanes take row r of two neighbouring 32-column chunks, so that they still WRITE 128
+// contiguous bytes of the LDS row (conflict-free, as in the row-major mapping) while a wave READS, per chunk, the 64-byte pieces
+// of 8 consecutive rows = 512 contiguous bytes.  (Odd chunk counts, W = 96: four lanes per row and chunk.)
+template <int W>
+__device__ __forceinline__ void blk_map(int c, int& row, int& col) {
+  if constexpr ((W / 32) % 2 == 0) {
+    row = (c >> 3) % WG_MSTEP;
+    col = (2 * ((c >> 3) / WG_MSTEP) + ((c >> 2) & 1)) * 32 + (c & 3) * 8;
+  } else {
+    row = (c >> 2) % WG_MSTEP;
+    col = ((c >> 2) / WG_MSTEP) * 32 + (c & 3) * 8;
+  }
+}
+
 template <int TN, int TK, bool PATCH, bool IMG = false, int WN = 2>
 __global__ __launch_bounds__(128 * WN) void wgrad_kernel(const WgradArgs g) {
   constexpr int NT = 128 * WN;
@@ -1243,9 +1258,8 @@ __global__ __launch_bounds__(128 * WN) void wgrad_kernel(const WgradArgs g) {
   for (int i = 0; i < CHY; ++i) {
     const int c = tid + i * NT;
     int col;
-    if (pr.y_blk) {       // chunk-major: four lanes read the 64 contiguous bytes of a row, consecutive rows are adjacent (a wave reads 1 KB runs)
-      y_row[i] = (c >> 2) % WG_MSTEP;
-      col = ((c >> 2) / WG_MSTEP) * 32 + (c & 3) * 8;
+    if (pr.y_blk) {       // chunk-major source: see blk_map
+      blk_map<TN>(c, y_row[i], col);
       ybase[i] = pr.dY + (size_t)((n0 + col) >> 5) * g.M * 32 + ((n0 + col) & 31);
     } else {
       y_row[i] = c / CPRY;
@@ -1264,8 +1278,7 @@ __global__ __launch_bounds__(128 * WN) void wgrad_kernel(const WgradArgs g) {
       a_row[i] = (c & 31) + 32 * row_hi;
       col = (pair * 2 + ((c >> 5) & 1)) * 8;
     } else if (pr.a_blk) {
-      a_row[i] = (c >> 2) % WG_MSTEP;
-      col = ((c >> 2) / WG_MSTEP) * 32 + (c & 3) * 8;
+      blk_map<TK>(c, a_row[i], col);
     } else {
       a_row[i] = c / CPRA;
       col = (c - a_row[i] * CPRA) * 8;

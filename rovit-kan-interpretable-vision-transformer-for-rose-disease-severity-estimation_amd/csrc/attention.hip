@@ -383,6 +383,183 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Backward, late round 3: ONE pass over the scores ("ring").  The two-pass kernel above computes S, P and dP twice, once in each
+// orientation, because dK / dV contract over the queries and dQ over the keys.  Here every wave owns 32 keys for the whole
+// launch (their K / V row fragments AND the transposed K fragments live in registers) and walks the seven 32-query blocks in a
+// ROTATED order -- in step t wave w works on query block (w + t) mod 7 -- so that in every step the seven waves hold seven
+// different query blocks.  Per step and wave: S and dP of (32 queries x 32 keys) once, one exp2 per score, dV and dK accumulated in
+// registers as before, and the block's dQ contribution added to a fp32 dQ tile in LDS that only this wave touches in this step
+// (one barrier per step hands the tiles on; the order of additions to a tile is fixed: wave (qb - t) mod 7 at step t, so the result
+// is bit-reproducible).  dS reaches the dQ product through a wave-private 32 x 32 bf16 patch in LDS (written in the accumulator
+// layout, read back transposed with ds_read_b64_tr_b16): 5 MFMA products and one exp2 per score instead of 7 and two.
+// LDS: Q and dO tiles (72 KB), the dQ tile (224 x 68 fp32 = 61 KB; the K tile is staged THERE first, only to be read back
+// transposed into registers), statistics, patches: 156 KB.  K and V tiles are never needed.
+// MEASURED (MI355X, batch 256): correct (tests/test_gpu_round3.py, every shape of the two-pass kernels' test) and SLOWER, 71 us
+// against 57-58 us, so it is opt-in (rovit_set_attn_bwd_pipe(2) / ROVIT_ATTN_BWD_PIPE=2).  Per step and CU the work is 280 MFMAs (1 280
+// matrix cycles per SIMD for its two waves), ~900 vector cycles and ~1 700 LDS cycles (the dQ read-modify-write alone: 56
+// ds_write_b128 at 13 cycles + 56 ds_read_b128; the patch; 140 transposed reads), and the barrier that hands the dQ tiles on keeps
+// the seven waves in LOCKSTEP, so these add up (2.4 us per step) instead of overlapping as they do between the free-running waves
+// of the two-pass kernel.  Fewer operations, worse overlap: the two-pass kernel stays the default.
+constexpr int DQ_ST = HD + 4;                  // fp32 row stride of the dQ tile (272 bytes)
+constexpr int DS_ST = 48;                      // bf16 row stride of a wave's dS patch (96 bytes: an odd multiple of 32)
+constexpr size_t ATTN_RING_LDS = (size_t)2 * TP * AST * sizeof(bf16) + (size_t)TP * DQ_ST * sizeof(float) + 2 * TP * sizeof(float) +
+                                 (size_t)NW * 32 * DS_ST * sizeof(bf16);
+static_assert((size_t)TP * AST * sizeof(bf16) <= (size_t)TP * DQ_ST * sizeof(float), "the K tile is staged inside the dQ tile");
+__device__ __forceinline__ bf16x8 col_frag_s(const bf16* tile, int stride, int r0, int dt, int l15, int lg) {
+  const bf16* p = tile + (r0 + 4 * lg + (l15 >> 2)) * stride + dt * 16 + 4 * (l15 & 3);
+  return cat4(lds_read_tr(p), lds_read_tr(p + 16 * stride));
+}
+
+__global__ __launch_bounds__(NW * 64) void attn_bwd_ring_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) bf16 lds[];
+  bf16* Qs = lds;
+  bf16* Gs = Qs + TP * AST;                     // dO
+  float* dQa = (float*)(Gs + TP * AST);         // [TP][DQ_ST]
+  float* s_lse = dQa + TP * DQ_ST;              // [TP]
+  float* s_del = s_lse + TP;                    // [TP]
+  bf16* Ka = (bf16*)dQa;                        // K tile [TP][AST], only until the transposed fragments are in registers
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  bf16* patch = (bf16*)(s_del + TP) + w * 32 * DS_ST;
+  const int ld = 3 * a.H * HD, ldo = a.H * HD;
+  const bf16* base = a.qkv + (size_t)b * a.T * ld + h * HD;
+  const bf16* gbase = a.dout + (size_t)b * a.T * ldo + h * HD;
+  const bf16* obase = a.out + (size_t)b * a.T * ldo + h * HD;
+  stage_tile(Qs, base, ld, a.T, tid);
+  stage_tile(Gs, gbase, ldo, a.T, tid);
+  stage_tile(Ka, base + a.H * HD, ld, a.T, tid);
+  bf16x8 kf[2][2], vf[2][2];                    // this wave's 32 keys as MFMA operands (zero rows beyond T)
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int kr = 32 * w + 16 * kt + l15;
+    const int kc = kr < a.T ? kr : a.T - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[kt][ks] = keep_if(*(const bf16x8*)(base + a.H * HD + (size_t)kc * ld + ks * 32 + lg * 8), kr < a.T);
+      vf[kt][ks] = keep_if(*(const bf16x8*)(base + 2 * a.H * HD + (size_t)kc * ld + ks * 32 + lg * 8), kr < a.T);
+    }
+  }
+  {
+    const int row = tid >> 1, half = tid & 1;     // 448 threads = 224 rows x 2 halves
+    float d = 0.f;
+    if (row < a.T) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8 g = *(const bf16x8*)(gbase + (size_t)row * ldo + half * 32 + i * 8);
+        const bf16x8 o = *(const bf16x8*)(obase + (size_t)row * ldo + half * 32 + i * 8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d = fmaf((float)g[q], (float)o[q], d);
+      }
+    }
+    d += __shfl_xor(d, 1);
+    if (half == 0) {
+      s_del[row] = -d;                          // initial accumulator of the dP chain (see attn_bwd_kernel)
+      s_lse[row] = row < a.T ? a.lse2[((size_t)b * a.H + h) * a.T + row] + 3.f : 3.f;      // + 3: P comes out times scale = 2^-3
+    }
+  }
+  __syncthreads();
+  bf16x8 kT[4];                                 // K^T of the wave's keys: rows = d, contraction slots = the 32 keys
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) kT[dt] = col_frag(Ka, 32 * w, dt, l15, lg);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                               // nobody reads the K tile any more: its space is the dQ tile from here on
+  for (int i = tid; i < TP * DQ_ST / 4; i += NW * 64) ((f32x4*)dQa)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};      // (every step adds: no first-visitor branch)
+  __syncthreads();
+  const float c2 = a.scale * LOG2E;
+  static_assert(HD == 64, "scale = 2^-3 is folded into the exponent offset");
+  f32x4 dv[4][2], dk[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) { dv[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+  for (int t = 0; t < 7; ++t) {
+    const int qb = w + t >= 7 ? w + t - 7 : w + t;
+    // ---- S and dP - delta: rows q = 32qb + 16qt + 4lg + r, col key = 32w + 16kt + l15 ----
+    f32x4 p[2][2], ds[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int qr = 32 * qb + 16 * qt + l15;
+      const bf16x8 q0 = row_frag(Qs, qr, 0, lg), q1 = row_frag(Qs, qr, 1, lg);
+      const bf16x8 g0 = row_frag(Gs, qr, 0, lg), g1 = row_frag(Gs, qr, 1, lg);
+      const float4 del4 = *(const float4*)(s_del + 32 * qb + 16 * qt + 4 * lg);
+      const float4 lse4 = *(const float4*)(s_lse + 32 * qb + 16 * qt + 4 * lg);
+      const f32x4 nd = {del4.x, del4.y, del4.z, del4.w};
+      const float lse_r[4] = {lse4.x, lse4.y, lse4.z, lse4.w};
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+        sc = mfma16(q0, kf[kt][0], sc);
+        sc = mfma16(q1, kf[kt][1], sc);
+        f32x4 dp = mfma16(g0, vf[kt][0], nd);
+        dp = mfma16(g1, vf[kt][1], dp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -lse_r[r]));     // P scale
+          p[qt][kt][r] = pr;
+          ds[qt][kt][r] = pr * dp[r];                                               // scale P (dP - delta)
+        }
+      }
+    }
+    // ---- dS, transposed, for the dQ product: the wave's patch holds [key][query] ----
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) *(bf16x4*)(patch + (16 * kt + l15) * DS_ST + 16 * qt + 4 * lg) = pack4(ds[qt][kt]);
+    // ---- dV, dK (contraction over the block's queries) ----
+    bf16x8 pf[2], dsf[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) { pf[kt] = pack8(p[0][kt], p[1][kt]); dsf[kt] = pack8(ds[0][kt], ds[1][kt]); }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const bf16x8 gT = col_frag(Gs, 32 * qb, dt, l15, lg);       // rows = d, slots = queries
+      const bf16x8 qT = col_frag(Qs, 32 * qb, dt, l15, lg);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        dv[dt][kt] = mfma16(gT, pf[kt], dv[dt][kt]);              // dV^T[d][key] (x scale)
+        dk[dt][kt] = mfma16(qT, dsf[kt], dk[dt][kt]);             // dK^T[d][key]
+      }
+    }
+    // ---- dQ^T[d][q] += K^T dS^T (contraction over the wave's 32 keys), accumulated in the block's LDS tile ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the patch writes have landed
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const bf16x8 dsT = col_frag_s(patch, DS_ST, 0, qt, l15, lg);   // cols = the tile's 16 queries, slots = keys
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        float* ap = dQa + (32 * qb + 16 * qt + l15) * DQ_ST + 16 * dt + 4 * lg;
+        *(f32x4*)ap = mfma16(kT[dt], dsT, *(const f32x4*)ap);
+      }
+    }
+    __syncthreads();                                               // hand the dQ tiles (and nothing else) on
+  }
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int key = 32 * w + 16 * kt + l15;
+    if (key < a.T) {
+      bf16* dst = a.dqkv + ((size_t)b * a.T + key) * ld + h * HD + 4 * lg;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        f32x4 v = dv[dt][kt];
+        v[0] *= 8.f; v[1] *= 8.f; v[2] *= 8.f; v[3] *= 8.f;
+        *(bf16x4*)(dst + a.H * HD + 16 * dt) = pack4(dk[dt][kt]);
+        *(bf16x4*)(dst + 2 * a.H * HD + 16 * dt) = pack4(v);
+      }
+    }
+  }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int qr = 32 * w + 16 * qt + l15;
+    if (qr < a.T) {
+      bf16* dst = a.dqkv + ((size_t)b * a.T + qr) * ld + h * HD + 4 * lg;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(dst + 16 * dt) = pack4(*(const f32x4*)(dQa + qr * DQ_ST + 16 * dt + 4 * lg));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Backward, round 3: the same two passes and the same arithmetic (bit-identical dQ / dK / dV), but PERSISTENT workgroups whose
 // tiles arrive by LDS-DMA (global_load_lds_dwordx4) while a pass computes.  The kernel above stages four tiles (143 KB, one
 // workgroup per CU), computes, exits: an HBM-bound staging burst and a compute phase strictly alternate (62 us at batch 256
@@ -808,8 +985,8 @@ static int g_attn_dbg = 0;
 // plus the exponentials and ~1000 non-loop instructions per item), the tile refills add 10 us and the stores 8 us ON TOP of
 // them although every refill is issued a pass ahead -- with all 256 workgroups in lockstep the chip sees 13 MB request bursts
 // whose delivery (3-5 us) is longer than the pass they were meant to hide behind.  Environment ROVIT_ATTN_BWD_PIPE=1 enables it.
-static int g_attn_bwd_pipe = [] { const char* e = getenv("ROVIT_ATTN_BWD_PIPE"); return (e && e[0] == '1') ? 1 : 0; }();
-extern "C" int rovit_set_attn_bwd_pipe(int on) { g_attn_bwd_pipe = on ? 1 : 0; return ROVIT_OK; }
+static int g_attn_bwd_pipe = [] { const char* e = getenv("ROVIT_ATTN_BWD_PIPE"); return e ? atoi(e) : 0; }();   // 0 two passes, 1 persistent, 2 ring
+extern "C" int rovit_set_attn_bwd_pipe(int on) { g_attn_bwd_pipe = on; return ROVIT_OK; }
 extern "C" int rovit_set_attn_debug(int d) { g_attn_dbg = d; return ROVIT_OK; }
 
 extern "C" int rovit_attention_probs(const void* qkv, float* probs, int batch, int tokens, int heads, int head_dim, float scale,
@@ -851,7 +1028,13 @@ extern "C" int rovit_attention_bwd(const void* qkv, const void* out, const float
   a.dout = (const bf16*)dout; a.dqkv = (bf16*)dqkv; a.dbg = g_attn_dbg;
   // round 3 (opt-in, see g_attn_bwd_pipe): persistent workgroups, tiles by LDS-DMA one phase ahead (attn_bwd_pipe_kernel);
   // ROVIT_ATTN_BWD_WGS=n: workgroups of the persistent launch (default: one per CU)
-  const bool use_pipe = g_attn_bwd_pipe != 0;
+  if (g_attn_bwd_pipe == 2) {
+    ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)attn_bwd_ring_kernel, ATTN_RING_LDS), ROVIT_ERR_LAUNCH, "attention_bwd: cannot raise the LDS limit");
+    hipLaunchKernelGGL(attn_bwd_ring_kernel, dim3(batch * heads), dim3(NW * 64), ATTN_RING_LDS, (hipStream_t)stream, a);
+    ROVIT_CHECK_LAUNCH("attn_bwd_ring_kernel");
+    return ROVIT_OK;
+  }
+  const bool use_pipe = g_attn_bwd_pipe == 1;
   static const int wgs_env = getenv("ROVIT_ATTN_BWD_WGS") ? atoi(getenv("ROVIT_ATTN_BWD_WGS")) : 256;
   if (use_pipe) {
     const int items = batch * heads;

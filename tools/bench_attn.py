@@ -52,10 +52,11 @@ def main():
     res = {'batch': B, 'ROVIT_ATTN_BWD_WGS': os.environ.get('ROVIT_ATTN_BWD_WGS', '256')}
     for rep in range(3):
         res.setdefault('fwd_us', []).append(round(timed(fwd), 2))
-        for pipe in (1, 0):
+        for pipe in (2, 1, 0):
             lib.rovit_set_attn_bwd_pipe(pipe)
-            res.setdefault('bwd_us_pipe' if pipe else 'bwd_us_staged', []).append(round(timed(bwd), 2))
-            res.setdefault('bwd_b2b_us_pipe' if pipe else 'bwd_b2b_us_staged', []).append(round(timed(bwd, per_launch=False), 2))
+            name = {0: 'staged', 1: 'pipe', 2: 'ring'}[pipe]
+            res.setdefault('bwd_us_' + name, []).append(round(timed(bwd), 2))
+            res.setdefault('bwd_b2b_us_' + name, []).append(round(timed(bwd, per_launch=False), 2))
     lib.rovit_set_attn_bwd_pipe(1)          # the ablations below are of the pipelined kernel
     for bits, name in ((1, 'bwd_us_no_pass1'), (2, 'bwd_us_no_pass2'), (3, 'bwd_us_no_passes'), (4, 'bwd_us_no_tile_loads'), (8, 'bwd_us_no_stores'), (12, 'bwd_us_compute_only'), (15, 'bwd_us_empty')):
         lib.rovit_set_attn_debug(bits)

@@ -165,6 +165,25 @@ __global__ __launch_bounds__(NW * 64, ROVIT_LB_ATTN_FWD) void attn_fwd_kernel(co
   }
 }
 
+// Transposed operand reads ISSUED EARLY (inline asm: hipcc otherwise sinks each ds_read_b64_tr_b16 pair to just in front of the MFMA
+// that uses it, and the dV / dK step of pass 1 then runs at LDS latency: ~1 170 cycles per query block for 256 cycles of MFMAs).  The
+// asm reads are invisible to the compiler's lgkmcnt bookkeeping (extra outstanding reads only make its own counted waits more
+// conservative), so tr_wait() -- lgkmcnt(0) + a scheduling fence -- must stand between tr_issue() and the first use of tr_val().
+struct TrFrag { bf16x4 lo, hi; };
+__device__ __forceinline__ TrFrag tr_issue(const bf16* tile, int r0, int dt, int l15, int lg) {
+  const bf16* p = tile + (r0 + 4 * lg + (l15 >> 2)) * AST + dt * 16 + 4 * (l15 & 3);
+  const unsigned a0 = (unsigned)(size_t)(const __attribute__((address_space(3))) bf16*)p;
+  TrFrag f;
+  static_assert(16 * AST * sizeof(bf16) == 2560, "offset of the second row block");
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2560" : "=&v"(f.lo), "=&v"(f.hi) : "v"(a0) : "memory");
+  return f;
+}
+__device__ __forceinline__ void tr_wait() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ bf16x8 tr_val(const TrFrag& f) { return cat4(f.lo, f.hi); }
+
 // Backward.  Pass 1: wave w owns keys [32w, 32w+32) -> dK, dV (loop over query blocks).
 //            Pass 2: wave w owns queries [32w, 32w+32) -> dQ (loop over key blocks).
 // Each pass recomputes the probabilities it needs from Q, K and lse2 in the orientation that makes them the
@@ -267,6 +286,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const AttnArgs a) {
     stepA(0, sb[0], dpb[0]);
 #pragma unroll
     for (int qb = 0; qb < 7; ++qb) {
+      TrFrag cg[4], cq[4];                       // operands of the dV / dK step: requested now, used behind the vector step
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { cg[dt] = tr_issue(Gs, 32 * qb, dt, l15, lg); cq[dt] = tr_issue(Qs, 32 * qb, dt, l15, lg); }
       if (qb + 1 < 7) stepA(qb + 1, sb[(qb + 1) & 1], dpb[(qb + 1) & 1]);
       f32x4 p[2][2], ds[2][2];
 #pragma unroll
@@ -285,10 +307,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const AttnArgs a) {
       bf16x8 pf[2], dsf[2];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) { pf[kt] = pack8(p[0][kt], p[1][kt]); dsf[kt] = pack8(ds[0][kt], ds[1][kt]); }
+      tr_wait();
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 gT = col_frag(Gs, 32 * qb, dt, l15, lg);     // rows = d, slots = queries
-        const bf16x8 qT = col_frag(Qs, 32 * qb, dt, l15, lg);
+        const bf16x8 gT = tr_val(cg[dt]);                         // rows = d, slots = queries
+        const bf16x8 qT = tr_val(cq[dt]);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
           dv[dt][kt] = mfma16(gT, pf[kt], dv[dt][kt]);            // dV^T[d][key] (x scale)
@@ -351,6 +374,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const AttnArgs a) {
     stepA(0, sb[0], dpb[0]);
 #pragma unroll
     for (int kb = 0; kb < 7; ++kb) {
+      TrFrag ck[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) ck[dt] = tr_issue(Ks, 32 * kb, dt, l15, lg);
       if (kb + 1 < 7) stepA(kb + 1, sb[(kb + 1) & 1], dpb[(kb + 1) & 1]);
       f32x4 ds[2][2];
 #pragma unroll
@@ -363,9 +389,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const AttnArgs a) {
       bf16x8 dsf[2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) dsf[qt] = pack8(ds[0][qt], ds[1][qt]);
+      tr_wait();
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 kT = col_frag(Ks, 32 * kb, dt, l15, lg);     // rows = d, slots = keys
+        const bf16x8 kT = tr_val(ck[dt]);                         // rows = d, slots = keys
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) dq[dt][qt] = mfma16(kT, dsf[qt], dq[dt][qt]);   // dQ^T[d][q]
       }

@@ -170,8 +170,11 @@ __global__ __launch_bounds__(NW * 64, ROVIT_LB_ATTN_FWD) void attn_fwd_kernel(co
 // asm reads are invisible to the compiler's lgkmcnt bookkeeping (extra outstanding reads only make its own counted waits more
 // conservative), so tr_wait() -- lgkmcnt(0) + a scheduling fence -- must stand between tr_issue() and the first use of tr_val().
 struct TrFrag { bf16x4 lo, hi; };
+// Column order: output tile dt of the product holds the tile's LDS columns 32 (dt >> 1) + 8 i + 4 (dt & 1) + j on its rows 4 i + j, so that a
+// lane's accumulators of the tile pair (2k, 2k + 1) are EIGHT CONSECUTIVE head-dim values 32 k + 8 lg .. + 7 of its row: one 16-byte store
+// instead of two 8-byte ones (the dK / dV / dQ stores cost ~6 us of the launch in 24 eight-byte store instructions per wave).
 __device__ __forceinline__ TrFrag tr_issue(const bf16* tile, int r0, int dt, int l15, int lg) {
-  const bf16* p = tile + (r0 + 4 * lg + (l15 >> 2)) * AST + dt * 16 + 4 * (l15 & 3);
+  const bf16* p = tile + (r0 + 4 * lg + (l15 >> 2)) * AST + 32 * (dt >> 1) + 8 * (l15 & 3) + 4 * (dt & 1);
   const unsigned a0 = (unsigned)(size_t)(const __attribute__((address_space(3))) bf16*)p;
   TrFrag f;
   static_assert(16 * AST * sizeof(bf16) == 2560, "offset of the second row block");
@@ -323,13 +326,14 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const AttnArgs a) {
     for (int kt = 0; kt < 2; ++kt) {
       const int key = 32 * w + 16 * kt + l15;
       if (key < a.T) {
-        bf16* dst = a.dqkv + ((size_t)b * a.T + key) * ld + h * HD + 4 * lg;
+        bf16* dst = a.dqkv + ((size_t)b * a.T + key) * ld + h * HD + 8 * lg;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          f32x4 v = dv[dt][kt];
-          v[0] *= 8.f; v[1] *= 8.f; v[2] *= 8.f; v[3] *= 8.f;
-          *(bf16x4*)(dst + a.H * HD + 16 * dt) = pack4(dk[dt][kt]);
-          *(bf16x4*)(dst + 2 * a.H * HD + 16 * dt) = pack4(v);
+        for (int k = 0; k < 2; ++k) {             // tile pair (2k, 2k+1) = head-dim values 32k + 8lg .. +7 (see tr_issue)
+          f32x4 v0 = dv[2 * k][kt], v1 = dv[2 * k + 1][kt];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v0[r] *= 8.f; v1[r] *= 8.f; }      // dV summed P scale: x 8, exact
+          *(bf16x8*)(dst + a.H * HD + 32 * k) = pack8(dk[2 * k][kt], dk[2 * k + 1][kt]);
+          *(bf16x8*)(dst + 2 * a.H * HD + 32 * k) = pack8(v0, v1);
         }
       }
     }
@@ -401,9 +405,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const AttnArgs a) {
     for (int qt = 0; qt < 2; ++qt) {
       const int qr = 32 * w + 16 * qt + l15;
       if (qr < a.T) {
-        bf16* dst = a.dqkv + ((size_t)b * a.T + qr) * ld + h * HD + 4 * lg;
+        bf16* dst = a.dqkv + ((size_t)b * a.T + qr) * ld + h * HD + 8 * lg;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(dst + 16 * dt) = pack4(dq[dt][qt]);
+        for (int k = 0; k < 2; ++k) *(bf16x8*)(dst + 32 * k) = pack8(dq[2 * k][qt], dq[2 * k + 1][qt]);
       }
     }
   }

@@ -197,6 +197,16 @@ size_t rovit_mlp_stream_bytes(void);
 int rovit_mlp_prepare_stream(const void* w1f, const void* w2, void* wstream, rovit_stream_t stream);
 int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const float* b1, const float* b2, void* act, void* dact, float* X,
                         void* xhat_out, float* rstd_out, float eps, int M, int act_rows, rovit_stream_t stream);
+/* Everything of a block behind the attention in ONE launch (timm Block: x = x + proj(attn(norm1 x)); x = x + mlp(norm2 x); then the next
+ * block's norm1 -- models/backbone.py:23-25):  X += o Wp^T + bp;  xhat2 / rstd2 = LayerNorm(X) (kept for the backward; NULL: inference);
+ * X += fc2(GELU(fc1(xhat2)));  xhat_out / rstd_out = LayerNorm(X) (NULL: none).  o: bf16 (M,192) attention output; wstream from
+ * rovit_mlp_prepare_stream_tail (w1f, w2 as rovit_mlp_prepare_stream; wproj = the bf16 (192,192) proj weight); act / dact chunk-major
+ * as rovit_mlp_fused_fwd.  The residual stream stays in fp32 registers between the halves (nothing staged through bf16: closer to the
+ * fp32 reference than proj + rovit_mlp_fused_fwd as two launches, not bit-identical to them). */
+int rovit_mlp_prepare_stream_tail(const void* w1f, const void* w2, const void* wproj, void* wstream, rovit_stream_t stream);
+int rovit_block_tail_fwd(const void* o, const void* wstream, const float* bp, const float* b1, const float* b2, float* X, void* xhat2,
+                         float* rstd2, void* act, void* dact, void* xhat_out, float* rstd_out, float eps, int M, int act_rows,
+                         rovit_stream_t stream);
 /* The dgrad chain of the same half in ONE launch (autograd of the above, training/trainer.py:119,136):
  *   dpre (M,768) = (dY (M,192) W2T^T) * dact        -- kept: the fc1 weight gradient reads it (bit-identical to rovit_gemm_nt(ROVIT_EPI_MUL))
  *   dX (M,192) += rstd2 (g - mean(g) - xhat2 mean(g xhat2)),  g = dpre W1T^T;   dXb = bf16(dX)     (= rovit_gemm_ln_bwd)

@@ -60,6 +60,16 @@ constexpr int NSLOT = 3;
 // independent streams of work (matrix, vector + LDS gather, matrix); 1: fc2 of chunk j - 1 behind its own GELU.
 constexpr int PSKEW = ROVIT_MLP_PIPE_SKEW;
 constexpr int PENTRIES = NCHUNK + PSKEW;
+// "block tail" forward (TAIL): the attention-output projection, its residual add and norm2 run IN FRONT of the MLP chain in the same
+// launch -- three more ring entries (the 192 x 192 proj weight as 12 output tiles x 6 k-steps) ahead of the skewed MLP image.  The
+// residual stream then never leaves the registers between the two halves: X is read once and written once per block (155 MB less
+// per block than proj + LayerNorm and the MLP half as two launches) and xhat2 is not read back.  Output tile ot of the proj product
+// (and, by the same permutation of its weight rows, of fc2) holds the columns tail_col(ot, row) on its accumulator rows, so that the
+// tile pair (2k, 2k+1) gives a lane EIGHT consecutive columns 32k + 8lg .. +7 of its token row: after norm2 those are, as they
+// stand, the fc1 B fragment of k-step k, and X / xhat leave as 32- / 16-byte runs.
+constexpr int TPROJ = 3;                      // ring entries of the proj weight
+constexpr int TENTRIES = TPROJ + PENTRIES;
+__host__ __device__ constexpr int tail_col(int ot, int row) { return 32 * (ot >> 1) + 8 * (row >> 2) + 4 * (ot & 1) + (row & 3); }
 constexpr int CSTR = 192 + 8;                 // staged output tile [ROWS][CSTR] bf16
 // NW waves per workgroup, 32 rows per wave.  NW = 8: one 256-row workgroup per CU.  NW = 4 (forward only): 128-row workgroups,
 // two per CU (76 KB each).  A backward slot also holds the workgroup's gelu' tile of the chunk (2 NW pieces).
@@ -84,6 +94,9 @@ struct MlpArgs {
   bf16* dact;             // forward gelu'(pre) (MODE == 2), chunk-major
   const bf16* mul;        // backward gelu'(pre), chunk-major [24][M][32]
   int act_rows;           // forward: rows of the whole chunk-major tensors (>= M: a launch may cover a row range of them)
+  const float* bp;        // TAIL: (192) proj bias
+  bf16* xhat2;            // TAIL: norm2 output (M,192) kept for the backward (NULL: inference)
+  float* rstd2;           // TAIL: (M)
   const bf16* gelu_table; // pipelined forward: the 32 KB table behind the two stream images
   float* X;               // (M,192) forward: residual stream; backward: dX; updated in place
   bf16* xhat;             // forward: next LayerNorm output or NULL; backward: xhat2 (input)
@@ -119,8 +132,10 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // the scheduler can put the vector work and the LDS gathers into the matrix pipe's shadow.  The GELU itself is a table look-up
 // (GT_*).  The first iterations' GELU / fc2 run on zeros and the last ones' fc1 on zero blocks; stores of chunks that do not
 // exist are sent out of range (dropped, but counted).
-template <int KIND, int MODE, int NW, bool STAG = false, bool PIPE = false>
+template <int KIND, int MODE, int NW, bool STAG = false, bool PIPE = false, bool TAIL = false>
 __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) {
+  static_assert(!TAIL || PIPE, "the block tail builds on the pipelined forward");
+  constexpr int NBIAS = HID + D + (TAIL ? D : 0);       // floats behind the ring: b1, b2 [, proj bias]
   static_assert(!STAG || (KIND == 0 && NW == 8), "the staggered schedule is the 8-wave forward's");
   static_assert(!PIPE || (KIND == 0 && NW == 8 && !STAG), "the pipelined schedule is the 8-wave forward's");
   constexpr int S = 2 * MODE;                 // stores one wave issues per chunk
@@ -156,19 +171,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
                                          (__attribute__((address_space(3))) void*)(lds + slot * SLOT + (CH_PIECES + w + NW * i) * PIECE), 16, 0, 0);
     }
   };
-  const bf16* gtab = lds + region_elems(KIND, NW) + 2 * (HID + D);     // PIPE: the GELU table (behind the biases)
-  if constexpr (PIPE) {
-    const bf16* src = g.gelu_table + lane * 8;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)                                          // 32 pieces of 1 KB: 8 waves x 4 (older than the ring's first DMA)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (r * NW + w) * PIECE),
-                                       (__attribute__((address_space(3))) void*)(lds + region_elems(KIND, NW) + 2 * (HID + D) + (r * NW + w) * PIECE), 16, 0, 0);
-  }
-  dma(0, 0);
-  dma(1, 1);
-
-  if (!KIND && tid < (HID + D) / 4) {             // biases -> LDS (240 float4)
-    const float4 v = tid < HID / 4 ? ((const float4*)g.b1)[tid] : ((const float4*)g.b2)[tid - HID / 4];
+  if (!KIND && tid < NBIAS / 4) {                 // biases -> LDS (240 / 288 float4)
+    const float4 v = tid < HID / 4 ? ((const float4*)g.b1)[tid] : tid < (HID + D) / 4 ? ((const float4*)g.b2)[tid - HID / 4]
+                                                                                       : ((const float4*)g.bp)[tid - (HID + D) / 4];
     ((float4*)s_bias)[tid] = v;
   }
   bf16x8 xf[2][6];
@@ -195,7 +200,26 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
 #pragma unroll
   for (int ot = 0; ot < 12; ++ot)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a2[ot][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 2; ++i) {
+      if constexpr (TAIL) {        // the residual stream itself, in the (permuted) accumulator layout: everything is accumulated onto it
+        const float4 x = *(const float4*)(g.X + (size_t)mcl[i] * D + tail_col(ot, 4 * lg));
+        a2[ot][i] = (f32x4){x.x, x.y, x.z, x.w};
+      } else {
+        a2[ot][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+
+  const bf16* gtab = lds + region_elems(KIND, NW) + 2 * NBIAS;       // PIPE: the GELU table (behind the biases)
+  if constexpr (PIPE) {
+    const bf16* src = g.gelu_table + lane * 8;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)                                          // 32 pieces of 1 KB: 8 waves x 4 (older than the ring's first DMA)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (r * NW + w) * PIECE),
+                                       (__attribute__((address_space(3))) void*)(lds + region_elems(KIND, NW) + 2 * NBIAS + (r * NW + w) * PIECE), 16, 0, 0);
+  }
+  // (the ring's first two entries are requested BEHIND the prologue's register loads: a wait for those then leaves the DMA in flight)
+  dma(0, 0);
+  dma(1, 1);
 
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // bias ds_writes retired before the first barrier
   if constexpr (STAG) {
@@ -327,16 +351,83 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
     bf16x8 pk[2] = {};               // bf16(pre-activation) of chunk j - 1: tile i, elements 4 t + r
     bf16x8 avo[2] = {};              // PSKEW = 2: gelu of chunk j - 2
     int slot = 0;
-#pragma unroll 1
-    for (int j = 0; j < PENTRIES; ++j) {
-      // issue order per iteration: [DMA(j+2): PW] [stores(j-1): S]: the same counts as the lockstep loop with PENTRIES entries
-      if (j == 0) wait_vm<PW>();
-      else if (j == 1) wait_vm<PW + S>();
-      else if (j < PENTRIES - 1) wait_vm<PW + 2 * S>();
+    constexpr int J0 = TAIL ? TPROJ : 0, NTOT = PENTRIES + J0;      // ring entries in front of the MLP image / in all
+    // every iteration issues [DMA(J+2): PW] [S stores] (iterations without real stores send theirs out of range: dropped, but
+    // counted), so the counted waits are those of the lockstep loop with NTOT entries
+    auto top = [&](int J) {
+      if (J == 0) wait_vm<PW>();
+      else if (J == 1) wait_vm<PW + S>();
+      else if (J < NTOT - 1) wait_vm<PW + 2 * S>();
       else wait_vm<2 * S>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (j + 2 < PENTRIES) dma(j + 2, slot == 0 ? 2 : slot - 1);
+      if (J + 2 < NTOT) dma(J + 2, slot == 0 ? 2 : slot - 1);
+    };
+    if constexpr (TAIL) {
+      // ---- the attention-output projection onto the residual stream: xf holds the attention output's fragments, a2 holds X ----
+#pragma unroll
+      for (int J = 0; J < TPROJ; ++J) {
+        top(J);
+        const bf16* sb = lds + slot * SLOT + lane * 8;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int ks = 0; ks < 6; ++ks) {
+            const bf16x8 wp = *(const bf16x8*)(sb + (6 * u + ks) * PIECE);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a2[4 * J + u][i] = mfma16(wp, xf[i][ks], a2[4 * J + u][i]);
+          }
+        {
+          const u32x4v z = {0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            if (MODE >= 1) __builtin_amdgcn_raw_buffer_store_b128(z, r_act, 0xFFFFFF00u, 0, 0);
+            if (MODE == 2) __builtin_amdgcn_raw_buffer_store_b128(z, r_dact, 0xFFFFFF00u, 0, 0);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        slot = slot == 2 ? 0 : slot + 1;
+      }
+      // ---- + proj bias; norm2 in registers; xhat2 = the fc1 B fragments; then + fc2 bias (fc2 accumulates on top) ----
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float sum = 0.f;
+#pragma unroll
+        for (int ot = 0; ot < 12; ++ot) {
+          const f32x4 b = *(const f32x4*)(s_bias + HID + D + tail_col(ot, 4 * lg));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { a2[ot][i][r] += b[r]; sum += a2[ot][i][r]; }
+        }
+        const float mean = group4_sum(sum) * (1.f / 192.f);
+        float qs = 0.f;
+#pragma unroll
+        for (int ot = 0; ot < 12; ++ot)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float v = a2[ot][i][r] - mean; qs += v * v; }
+        const float rs = rsqrtf(group4_sum(qs) * (1.f / 192.f) + g.eps);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          f32x4 lo, hi;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { lo[r] = (a2[2 * k][i][r] - mean) * rs; hi[r] = (a2[2 * k + 1][i][r] - mean) * rs; }
+          xf[i][k] = pack8(lo, hi);
+        }
+        if (g.xhat2 && mrow[i] < g.M) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) *(bf16x8*)(g.xhat2 + (size_t)mrow[i] * D + 32 * k + 8 * lg) = xf[i][k];
+          if (lg == 0) g.rstd2[mrow[i]] = rs;
+        }
+#pragma unroll
+        for (int ot = 0; ot < 12; ++ot) {
+          const f32x4 b = *(const f32x4*)(s_bias + HID + tail_col(ot, 4 * lg));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a2[ot][i][r] += b[r];
+        }
+      }
+    }
+#pragma unroll 1
+    for (int j = 0; j < PENTRIES; ++j) {
+      top(j + J0);
       const bf16* sb = lds + slot * SLOT + lane * 8;
       const int cb = j < NCHUNK ? j : NCHUNK - 1;             // bias row of a real chunk (the products of the last PSKEW iterations are discarded)
       f32x4 a1[2][2];
@@ -514,6 +605,46 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
 
   }
 
+  if constexpr (TAIL) {
+    // ---- a2 IS the updated residual stream (fp32, nothing staged through bf16): next LayerNorm in registers, 32- / 16-byte stores ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float mean = 0.f, rs = 0.f;
+      if (g.xhat) {
+        float sum = 0.f;
+#pragma unroll
+        for (int ot = 0; ot < 12; ++ot)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sum += a2[ot][i][r];
+        mean = group4_sum(sum) * (1.f / 192.f);
+        float qs = 0.f;
+#pragma unroll
+        for (int ot = 0; ot < 12; ++ot)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float v = a2[ot][i][r] - mean; qs += v * v; }
+        rs = rsqrtf(group4_sum(qs) * (1.f / 192.f) + g.eps);
+      }
+      if (mrow[i] < g.M) {
+        float* xp = g.X + (size_t)mrow[i] * D;
+#pragma unroll
+        for (int ot = 0; ot < 12; ++ot) {
+          const f32x4 v = a2[ot][i];
+          *(float4*)(xp + tail_col(ot, 4 * lg)) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (g.xhat) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            f32x4 lo, hi;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { lo[r] = (a2[2 * k][i][r] - mean) * rs; hi[r] = (a2[2 * k + 1][i][r] - mean) * rs; }
+            *(bf16x8*)(g.xhat + (size_t)mrow[i] * D + 32 * k + 8 * lg) = pack8(lo, hi);
+          }
+          if (lg == 0) g.rstd[mrow[i]] = rs;
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue: bf16(out [+ b2]) staged in LDS (aliases the ring: every wave must have left the loop) ----
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -644,10 +775,13 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
 // Weight stream of one block: chunk c (hidden units 32 c .. 32 c + 31) = 24 pieces of 64 x 16 bytes;
 //   piece 6 t + ks (t = 0, 1; ks = 0..5): lane (l15, lg) = W1f[32 c + 8 (l15 >> 2) + 4 t + (l15 & 3)][32 ks + 8 lg .. +7]
 //   piece 12 + ot  (ot = 0..11):         lane (l15, lg) = W2[16 ot + l15][32 c + 8 lg .. +7]
-struct MlpPrepArgs { const char* base; size_t blk0, stride, off_w1, off_w2, off_out; };
-// The stream buffer holds TWO images: the plain one (NCHUNK entries) and, behind it, the SKEWED one of the pipelined forward
-// (PENTRIES entries: entry j = fc1 fragments of chunk j | fc2 fragments of chunk j - PSKEW; the missing halves are zeros).
-constexpr int STREAM_ENTRIES = NCHUNK + PENTRIES;
+struct MlpPrepArgs { const char* base; size_t blk0, stride, off_w1, off_w2, off_out, off_wp; };     // off_wp: proj weight, or NO_WP
+constexpr size_t NO_WP = ~(size_t)0;
+// The stream buffer holds THREE images and the GELU table: the plain one (NCHUNK entries), the SKEWED one of the pipelined forward
+// (PENTRIES entries: entry j = fc1 fragments of chunk j | fc2 fragments of chunk j - PSKEW; the missing halves are zeros) and the
+// BLOCK-TAIL one (TENTRIES entries: TPROJ entries of proj-weight fragments, output tile ot = rows tail_col(ot, .) of the weight, then the
+// skewed image with the rows of the fc2 fragments permuted the same way; zeros when no proj weight is given).
+constexpr int STREAM_ENTRIES = NCHUNK + PENTRIES + TENTRIES;
 __global__ __launch_bounds__(256) void mlp_stream_prep_kernel(const MlpPrepArgs a) {
   const int blk = blockIdx.y;
   const char* q = a.base + a.blk0 + (size_t)blk * a.stride;
@@ -658,19 +792,40 @@ __global__ __launch_bounds__(256) void mlp_stream_prep_kernel(const MlpPrepArgs 
   if (e >= STREAM_ENTRIES * CH_PIECES * 64) return;
   const int lane = e & 63, piece = (e >> 6) % CH_PIECES, entry = e / (64 * CH_PIECES);
   const int l15 = lane & 15, lg = lane >> 4;
-  int c = entry;                                          // hidden chunk this piece belongs to
-  if (entry >= NCHUNK) c = entry - NCHUNK - (piece < 12 ? 0 : PSKEW);
   bf16x8 v = {};
-  if (c >= 0 && c < NCHUNK) {
-    const bf16* src;
-    if (piece < 12) {
-      const int t = piece / 6, ks = piece - 6 * t;
-      src = w1 + (size_t)(HC * c + 8 * (l15 >> 2) + 4 * t + (l15 & 3)) * D + 32 * ks + 8 * lg;
-    } else {
-      src = w2 + (size_t)(16 * (piece - 12) + l15) * HID + HC * c + 8 * lg;
+  const bf16* src = nullptr;
+  if (entry >= NCHUNK + PENTRIES) {                       // block-tail image
+    const int t = entry - (NCHUNK + PENTRIES);
+    if (a.off_wp != NO_WP) {
+      if (t < TPROJ) {
+        const bf16* wp = (const bf16*)(q + a.off_wp);
+        const int ot = 4 * t + piece / 6, ks = piece % 6;
+        src = wp + (size_t)tail_col(ot, l15) * D + 32 * ks + 8 * lg;
+      } else {
+        const int c = t - TPROJ - (piece < 12 ? 0 : PSKEW);
+        if (c >= 0 && c < NCHUNK) {
+          if (piece < 12) {
+            const int tt = piece / 6, ks = piece - 6 * tt;
+            src = w1 + (size_t)(HC * c + 8 * (l15 >> 2) + 4 * tt + (l15 & 3)) * D + 32 * ks + 8 * lg;
+          } else {
+            src = w2 + (size_t)tail_col(piece - 12, l15) * HID + HC * c + 8 * lg;
+          }
+        }
+      }
     }
-    v = *(const bf16x8*)src;
+  } else {
+    int c = entry;                                        // hidden chunk this piece belongs to
+    if (entry >= NCHUNK) c = entry - NCHUNK - (piece < 12 ? 0 : PSKEW);
+    if (c >= 0 && c < NCHUNK) {
+      if (piece < 12) {
+        const int t = piece / 6, ks = piece - 6 * t;
+        src = w1 + (size_t)(HC * c + 8 * (l15 >> 2) + 4 * t + (l15 & 3)) * D + 32 * ks + 8 * lg;
+      } else {
+        src = w2 + (size_t)(16 * (piece - 12) + l15) * HID + HC * c + 8 * lg;
+      }
+    }
   }
+  if (src) v = *(const bf16x8*)src;
   *(bf16x8*)(out + (size_t)e * 8) = v;
 }
 
@@ -727,8 +882,8 @@ extern "C" size_t rovit_mlp_stream_bytes(void) { return (size_t)STREAM_ENTRIES *
 
 // (internal) streams of `depth` blocks laid out inside the prepared-weight buffer of rovit_vit_prepare
 int rovit_mlp_stream_prep_blocks(const void* prep_base, size_t blk0, size_t stride, size_t off_w1, size_t off_w2, size_t off_out,
-                                 int depth, rovit_stream_t stream) {
-  const MlpPrepArgs a{(const char*)prep_base, blk0, stride, off_w1, off_w2, off_out};
+                                 size_t off_wp, int depth, rovit_stream_t stream) {
+  const MlpPrepArgs a{(const char*)prep_base, blk0, stride, off_w1, off_w2, off_out, off_wp};
   hipLaunchKernelGGL(mlp_stream_prep_kernel, dim3((STREAM_ENTRIES * CH_PIECES * 64 + 255) / 256, depth), dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(mlp_gelu_table_kernel, dim3(GT_ENTRIES / 256, depth), dim3(256), 0, (hipStream_t)stream, a);
   ROVIT_CHECK_LAUNCH("mlp_stream_prep_kernel");
@@ -737,11 +892,21 @@ int rovit_mlp_stream_prep_blocks(const void* prep_base, size_t blk0, size_t stri
 
 // w1f: bf16 (768,192) fc1 weight with the LayerNorm affine folded in (rovit_prep_weight's Wf); w2: bf16 (192,768) fc2 weight;
 // wstream: rovit_mlp_stream_bytes() bytes, 16-byte aligned.
+static int mlp_prepare_stream_impl(const void* w1f, const void* w2, const void* wproj, void* wstream, rovit_stream_t stream);
 extern "C" int rovit_mlp_prepare_stream(const void* w1f, const void* w2, void* wstream, rovit_stream_t stream) {
+  return mlp_prepare_stream_impl(w1f, w2, nullptr, wstream, stream);
+}
+// ... with the block-tail image too (rovit_block_tail_fwd): wproj = the bf16 attention-output projection weight (192,192)
+extern "C" int rovit_mlp_prepare_stream_tail(const void* w1f, const void* w2, const void* wproj, void* wstream, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(wproj && rovit_aligned16(wproj), ROVIT_ERR_NULL, "mlp_prepare_stream_tail: wproj missing or misaligned");
+  return mlp_prepare_stream_impl(w1f, w2, wproj, wstream, stream);
+}
+static int mlp_prepare_stream_impl(const void* w1f, const void* w2, const void* wproj, void* wstream, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(w1f && w2 && wstream, ROVIT_ERR_NULL, "mlp_prepare_stream: null pointer");
   ROVIT_CHECK_ARG(rovit_aligned16(w1f) && rovit_aligned16(w2) && rovit_aligned16(wstream), ROVIT_ERR_ALIGN, "mlp_prepare_stream: alignment");
-  // one "block" whose three fields are addressed relative to w1f
-  const MlpPrepArgs a{(const char*)w1f, 0, 0, 0, (size_t)((const char*)w2 - (const char*)w1f), (size_t)((char*)wstream - (const char*)w1f)};
+  // one "block" whose fields are addressed relative to w1f
+  const MlpPrepArgs a{(const char*)w1f, 0, 0, 0, (size_t)((const char*)w2 - (const char*)w1f), (size_t)((char*)wstream - (const char*)w1f),
+                      wproj ? (size_t)((const char*)wproj - (const char*)w1f) : NO_WP};
   hipLaunchKernelGGL(mlp_stream_prep_kernel, dim3((STREAM_ENTRIES * CH_PIECES * 64 + 255) / 256, 1), dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(mlp_gelu_table_kernel, dim3(GT_ENTRIES / 256, 1), dim3(256), 0, (hipStream_t)stream, a);
   ROVIT_CHECK_LAUNCH("mlp_stream_prep_kernel");
@@ -801,6 +966,42 @@ extern "C" int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const
   }
 #undef LAUNCH_MODE
   ROVIT_CHECK_LAUNCH("mlp_fused_kernel (forward)");
+  return ROVIT_OK;
+}
+
+// Everything of a block behind the attention in ONE launch ("block tail"; timm Block: x = x + proj(attn); x = x + mlp(norm2(x)); then
+// the next block's norm1 -- models/backbone.py:23-25):
+//   X (M,192) += o Wp^T + bp;  xhat2 / rstd2 = LayerNorm(X) (kept for the backward; NULL: inference);
+//   X += fc2(GELU(fc1(xhat2)));  xhat_out / rstd_out = LayerNorm(X) (NULL: none).
+// o: bf16 (M,192) attention output; wstream: rovit_mlp_prepare_stream_tail's buffer; act / dact as rovit_mlp_fused_fwd (chunk-major).
+// The residual stream stays in fp32 registers between the two halves: nothing is staged through bf16, X is read and written once.
+extern "C" int rovit_block_tail_fwd(const void* o, const void* wstream, const float* bp, const float* b1, const float* b2, float* X,
+                                    void* xhat2, float* rstd2, void* act, void* dact, void* xhat_out, float* rstd_out, float eps, int M,
+                                    int act_rows, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(o && wstream && bp && b1 && b2 && X, ROVIT_ERR_NULL, "block_tail_fwd: null pointer");
+  ROVIT_CHECK_ARG(M > 0 && act_rows >= M && (size_t)act_rows * HID * 2 < ((size_t)1 << 31), ROVIT_ERR_SHAPE,
+                  "block_tail_fwd: M = %d, act_rows = %d out of range", M, act_rows);
+  ROVIT_CHECK_ARG(act || !dact, ROVIT_ERR_NULL, "block_tail_fwd: dact without act");
+  ROVIT_CHECK_ARG((!xhat_out || rstd_out) && (!xhat2 || rstd2), ROVIT_ERR_NULL, "block_tail_fwd: rstd output missing");
+  ROVIT_CHECK_ARG(rovit_aligned16(o) && rovit_aligned16(wstream) && rovit_aligned16(bp) && rovit_aligned16(b1) && rovit_aligned16(b2) &&
+                      rovit_aligned16(X) && rovit_aligned16(xhat2) && rovit_aligned16(act) && rovit_aligned16(dact) && rovit_aligned16(xhat_out),
+                  ROVIT_ERR_ALIGN, "block_tail_fwd: buffers must be 16-byte aligned");
+  MlpArgs g{};
+  g.xin = (const bf16*)o; g.b1 = b1; g.b2 = b2; g.bp = bp; g.act = (bf16*)act; g.dact = (bf16*)dact; g.xhat2 = (bf16*)xhat2; g.rstd2 = rstd2;
+  g.X = X; g.xhat = (bf16*)xhat_out; g.rstd = rstd_out; g.eps = eps; g.M = M; g.act_rows = act_rows;
+  g.gelu_table = (const bf16*)wstream + (size_t)STREAM_ENTRIES * CH_ELEMS;
+  g.wstream = (const bf16*)wstream + (size_t)(NCHUNK + PENTRIES) * CH_ELEMS;          // the block-tail image
+  const size_t lds = lds_bytes(0, 8) + D * sizeof(float) + GT_ENTRIES * 4;
+  const dim3 grid((M + 255) / 256), block(512);
+#define LAUNCH_TAIL(MD)                                                                                                          \
+  do {                                                                                                                           \
+    ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<0, MD, 8, false, true, true>, lds), ROVIT_ERR_LAUNCH,        \
+                    "block_tail_fwd: cannot raise the LDS limit");                                                               \
+    hipLaunchKernelGGL((mlp_fused_kernel<0, MD, 8, false, true, true>), grid, block, lds, (hipStream_t)stream, g);               \
+  } while (0)
+  if (!act) LAUNCH_TAIL(0); else if (!dact) LAUNCH_TAIL(1); else LAUNCH_TAIL(2);
+#undef LAUNCH_TAIL
+  ROVIT_CHECK_LAUNCH("mlp_fused_kernel (block tail)");
   return ROVIT_OK;
 }
 

@@ -257,8 +257,8 @@ extern "C" int rovit_vit_prepare(const float* const* params, void* prep, int dep
     descs.push_back({bp[B_FC2W], nullptr, nullptr, nullptr, q + P.wfc2, q + P.wfc2T, nullptr, D, MLP});
   }
   RUN(rovit_prep_weight_batch(descs.data(), (int)descs.size(), stream));
-  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc1, P.wfc2, P.wmlp, depth, stream));
-  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc2T, P.wfc1T, P.wmlpb, depth, stream));     // dgrad chain: (W2T, W1T)
+  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc1, P.wfc2, P.wmlp, P.wproj, depth, stream));     // + proj: the block-tail image
+  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc2T, P.wfc1T, P.wmlpb, ~(size_t)0, depth, stream));     // dgrad chain: (W2T, W1T), no tail image
   return ROVIT_OK;
 }
 
@@ -337,6 +337,21 @@ int vit_forward_impl(const float* images, const float* const* params, const void
     // ... and, separately, the softmax probabilities (B,3,197,197) the reference's rollout code means to collect
     // (explainability/attention_maps.py:18-105)
     if (prob_taps && prob_taps[i]) RUN(rovit_attention_probs(s + L.qkv, prob_taps[i], batch, T, H, D / H, 0.125f, stream));
+    // Everything behind the attention in ONE launch ("block tail", mlp_fused.hip: proj + residual + norm2 + MLP + residual + next
+    // norm1; the residual stream stays in registers between the halves).  ROVIT_BLOCK_TAIL=0: proj + norm2 as their own launch.
+    static const bool block_tail = !(getenv("ROVIT_BLOCK_TAIL") && getenv("ROVIT_BLOCK_TAIL")[0] == '0');
+    if (block_tail && !cls_only && mlp_one_launch((long)batch * T)) {
+      char* sn = ws + L.blk0 + (size_t)(i + 1) * L.blk_stride;            // next block's saved-activation area
+      EACH_HALF {
+        const Half& h = halves[hh];
+        float* Xh = X + (size_t)h.b0 * T * D;
+        RUN(rovit_block_tail_fwd(ROWS(s + L.o, D, 2), q + P.wmlp, bp[B_PROJB], (const float*)(q + P.bfc1), bp[B_FC2B], Xh,
+                                 training ? ROWS(s + L.xhat2, D, 2) : nullptr, training ? (float*)ROWS(s + L.rstd2, 1, 4) : nullptr,
+                                 training ? ROWS(s + L.act, 32, 2) : nullptr, training ? ROWS(s + L.dact, 32, 2) : nullptr,
+                                 ROWS(sn + L.xhat1, D, 2), (float*)ROWS(sn + L.rstd1, 1, 4), eps, h.nb * T, batch * T, h.st));
+      }
+      continue;
+    }
     EACH_HALF {
       const Half& h = halves[hh];
       float* Xh = X + (size_t)h.b0 * T * D;

@@ -142,6 +142,63 @@ def test_pipelined_mlp_half_gelu_table_and_its_fallback_on_special_inputs(M):
     assert float((X1 - Xr).abs().max()) < 2 ** -7 * max(float((X1 - X0).abs().max()), 1.0)
 
 
+@pytest.mark.parametrize('M', [1, 77, 256, 257, 1000, 197 * 20, 256 * 197])
+@pytest.mark.parametrize('train', [True, False])
+def test_block_tail_equals_proj_plus_mlp_half_and_a_torch_reference(M, train):
+    """rovit_block_tail_fwd = proj + residual + norm2 + MLP + residual + next norm1 in ONE launch, the residual stream held in fp32
+    registers between the halves.  Against the chain rovit_gemm_resid_ln (proj) -> rovit_mlp_fused_fwd it differs only by what those
+    stage through bf16 (the two branch outputs), i.e. X agrees to about one bf16 ulp of a branch output, and the LayerNorm outputs to a
+    neighbouring bf16 value; against a plain fp32 torch computation on the same bf16 operands it is the CLOSER of the two."""
+    native = _native()
+    g = torch.Generator(device='cpu').manual_seed(7000 + M)
+    r = lambda *s: torch.randn(*s, generator=g)
+    o = bf(r(M, 192)).to(dev())
+    wp = bf(r(192, 192) * 0.07).to(dev())
+    bp_ = (r(192) * 0.2).to(dev())
+    _, w1, w2, b1, b2, X0 = _mlp_problem(M, 7100 + M)
+    p, sp = native.ptr, native.stream_ptr()
+    lib = native.load()
+    # chain of the two existing launches
+    Xa = X0.clone()
+    xh2a = torch.empty(M, 192, device=dev(), dtype=torch.bfloat16)
+    r2a = torch.empty(M, device=dev())
+    native.call('rovit_gemm_resid_ln', p(o), 192, p(wp), 192, M, 192, p(bp_), p(Xa), p(xh2a), p(r2a), 1e-6, sp)
+    acta, dacta, Xa2, xh1a, r1a = _fused(native, xh2a, w1, w2, b1, b2, Xa)
+    # one launch
+    ws = torch.empty(lib.rovit_mlp_stream_bytes(), dtype=torch.uint8, device=dev())
+    native.call('rovit_mlp_prepare_stream_tail', p(w1), p(w2), p(wp), p(ws), sp)
+    nanb = lambda *s: torch.full(s, float('nan'), device=dev(), dtype=torch.bfloat16)
+    X = X0.clone()
+    xh2, r2 = (nanb(M, 192), torch.full((M,), float('nan'), device=dev())) if train else (None, None)
+    act, dact = (nanb(M, 768), nanb(M, 768)) if train else (None, None)
+    xh1, r1 = nanb(M, 192), torch.full((M,), float('nan'), device=dev())
+    native.call('rovit_block_tail_fwd', p(o), p(ws), p(bp_), p(b1), p(b2), p(X), p(xh2), p(r2), p(act), p(dact), p(xh1), p(r1), 1e-6, M, M, sp)
+    # fp32 reference on the same bf16 operands (xhat2 rounded to bf16 where the kernels round it)
+    Xm = X0 + o.float() @ wp.float().t() + bp_
+    ln = lambda t: torch.nn.functional.layer_norm(t, (192,), eps=1e-6)
+    xh2_ref = bf(ln(Xm))
+    pre = bf(xh2_ref.float() @ w1.float().t() + b1).float()
+    act_ref = torch.nn.functional.gelu(pre)
+    Xf = Xm + bf(act_ref).float() @ w2.float().t() + b2
+    br = float((Xf - X0).abs().max())
+    assert bool(torch.isfinite(X).all()) and bool(torch.isfinite(xh1.float()).all())
+    e_new, e_old = float((X - Xf).abs().max()), float((Xa2 - Xf).abs().max())
+    print('block tail: max |X - fp32 reference|', e_new, 'two launches', e_old, 'branch scale', br)
+    assert e_new < 2 ** -7 * max(br, 1.0)                       # a bf16 ulp of the branch sum: GELU rounding flips of single hidden units
+    assert float((X - Xa2).abs().max()) < 2 ** -6 * max(br, 1.0)
+    assert float((xh1.float() - ln(X)).abs().max()) < 2e-2
+    assert float(((r1 - 1 / torch.sqrt(X.var(1, unbiased=False) + 1e-6)).abs() / r1.abs()).max()) < 1e-5
+    if train:
+        assert float((xh2.float() - ln(Xm)).abs().max()) < 2e-2 and float((xh2.float() - xh2a.float()).abs().max()) < 4e-2
+        assert float(((r2 - 1 / torch.sqrt(Xm.var(1, unbiased=False) + 1e-6)).abs() / r2.abs()).max()) < 1e-4
+        a_rows, d_rows = _rows(act, M), _rows(dact, M)
+        # the kept activations are those of the xhat2 THIS launch normalised: recompute them from its own xhat2 with the two-launch GELU kernel
+        a_chk = torch.empty(M, 768, device=dev(), dtype=torch.bfloat16)
+        d_chk = torch.empty_like(a_chk)
+        native.call('rovit_gemm_nt', p(xh2), 192, p(w1), 192, M, 768, 192, p(b1), 1, p(a_chk), 768, p(d_chk), None, 0, None, 0, None, 0, sp)
+        assert torch.equal(a_rows.view(torch.int16), a_chk.view(torch.int16)) and torch.equal(d_rows.view(torch.int16), d_chk.view(torch.int16))
+
+
 def test_fused_mlp_half_on_row_ranges_of_one_chunk_major_tensor():
     """rovit_vit_forward runs the two half-batches as two launches that write row ranges of ONE chunk-major act / gelu' pair
     (pointers advanced by first_row x 32 elements, act_rows = rows of the whole): together they must equal one whole-batch launch."""
@@ -419,6 +476,8 @@ torch.save({'f': f.detach().cpu(), 'g': g.cpu()}, out)
     g1, g0 = res['1']['g'], res['0']['g']
     # the two builds differ only by fp32 summation order inside fc2 (an occasional neighbouring-bf16 rounding of a branch output)
     # (bf16 rounding flips propagate through 12 blocks: the two builds differ like either differs from the fp32 oracle)
-    assert float((f1 - f0).abs().max()) < 3e-2 and float((f1 - f0).pow(2).mean().sqrt()) < 6e-3
+    # (the one-launch build also keeps the residual stream in fp32 where the other stages two branch outputs through bf16: 6.1e-3 RMS
+    # between the builds after 12 blocks, each within the 8e-3 the tests allow against the fp32 oracle)
+    assert float((f1 - f0).abs().max()) < 3e-2 and float((f1 - f0).pow(2).mean().sqrt()) < 8e-3
     assert float(torch.nn.functional.cosine_similarity(g1, g0, dim=0)) > 0.9995
     assert float((g1 - g0).abs().max()) < 3e-2 * float(g0.abs().max())

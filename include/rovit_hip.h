@@ -207,6 +207,12 @@ int rovit_mlp_prepare_stream_tail(const void* w1f, const void* w2, const void* w
 int rovit_block_tail_fwd(const void* o, const void* wstream, const float* bp, const float* b1, const float* b2, float* X, void* xhat2,
                          float* rstd2, void* act, void* dact, void* xhat_out, float* rstd_out, float eps, int M, int act_rows,
                          rovit_stream_t stream);
+/* ... and the backward's counterpart: rovit_mlp_fused_bwd with the norm2 backward in registers and, behind it, the proj dgrad
+ * dO (M,192) = dXb Wproj in the same launch (dO NULL: none).  wstream_bwd from rovit_mlp_prepare_stream_tail_bwd(W2T, W1T folded,
+ * WprojT = the transposed bf16 proj weight). */
+int rovit_mlp_prepare_stream_tail_bwd(const void* w2T, const void* w1T, const void* wprojT, void* wstream, rovit_stream_t stream);
+int rovit_block_tail_bwd(const void* dY, const void* wstream_bwd, const void* dact, void* dpre, const void* xhat2, const float* rstd2,
+                         float* dX, void* dXb, void* dO, int M, rovit_stream_t stream);
 /* The dgrad chain of the same half in ONE launch (autograd of the above, training/trainer.py:119,136):
  *   dpre (M,768) = (dY (M,192) W2T^T) * dact        -- kept: the fc1 weight gradient reads it (bit-identical to rovit_gemm_nt(ROVIT_EPI_MUL))
  *   dX (M,192) += rstd2 (g - mean(g) - xhat2 mean(g xhat2)),  g = dpre W1T^T;   dXb = bf16(dX)     (= rovit_gemm_ln_bwd)

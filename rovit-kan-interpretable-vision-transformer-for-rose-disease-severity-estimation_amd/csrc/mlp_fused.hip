@@ -95,6 +95,7 @@ struct MlpArgs {
   const bf16* mul;        // backward gelu'(pre), chunk-major [24][M][32]
   int act_rows;           // forward: rows of the whole chunk-major tensors (>= M: a launch may cover a row range of them)
   const float* bp;        // TAIL: (192) proj bias
+  bf16* dO;               // backward TAIL: (M,192) gradient w.r.t. the attention output (= dXb Wproj), or NULL
   bf16* xhat2;            // TAIL: norm2 output (M,192) kept for the backward (NULL: inference)
   float* rstd2;           // TAIL: (M)
   const bf16* gelu_table; // pipelined forward: the 32 KB table behind the two stream images
@@ -134,7 +135,7 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // exist are sent out of range (dropped, but counted).
 template <int KIND, int MODE, int NW, bool STAG = false, bool PIPE = false, bool TAIL = false>
 __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) {
-  static_assert(!TAIL || PIPE, "the block tail builds on the pipelined forward");
+  static_assert(!TAIL || PIPE || KIND == 1, "the forward block tail builds on the pipelined forward");
   constexpr int NBIAS = HID + D + (TAIL ? D : 0);       // floats behind the ring: b1, b2 [, proj bias]
   static_assert(!STAG || (KIND == 0 && NW == 8), "the staggered schedule is the 8-wave forward's");
   static_assert(!PIPE || (KIND == 0 && NW == 8 && !STAG), "the pipelined schedule is the 8-wave forward's");
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
   for (int ot = 0; ot < 12; ++ot)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if constexpr (TAIL) {        // the residual stream itself, in the (permuted) accumulator layout: everything is accumulated onto it
+      if constexpr (TAIL && KIND == 0) {        // the residual stream itself, in the (permuted) accumulator layout: everything is accumulated onto it
         const float4 x = *(const float4*)(g.X + (size_t)mcl[i] * D + tail_col(ot, 4 * lg));
         a2[ot][i] = (f32x4){x.x, x.y, x.z, x.w};
       } else {
@@ -605,7 +606,89 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
 
   }
 
-  if constexpr (TAIL) {
+  if constexpr (TAIL && KIND == 1) {
+    // ---- backward block tail: a2 = dxhat2^T in the permuted layout (the stream's second-GEMM rows are permuted by tail_col): norm2
+    // backward in registers (fp32 dxhat2, nothing staged through bf16), dX / dXb leave as 32- / 16-byte runs, and the bf16 dX tile
+    // pairs are, as they stand, the B fragments of the proj dgrad dO = dXb Wproj, whose weight fragments are the image's last three
+    // entries (requested only now: the ring is idle, the epilogue's register loads have been consumed) ----
+    __builtin_amdgcn_s_barrier();                               // every wave has left the loop: the slots are free
+    asm volatile("" ::: "memory");
+    if (g.dO) {                                                 // the proj dgrad's weight fragments travel while the norm2 backward runs
+#pragma unroll
+      for (int e = 0; e < TPROJ; ++e) {
+        const bf16* src = g.wstream + (size_t)(NCHUNK + e) * CH_ELEMS + lane * 8;
+#pragma unroll
+        for (int q = 0; q < CH_PIECES / NW; ++q) {
+          const int piece = w + NW * q;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * PIECE),
+                                           (__attribute__((address_space(3))) void*)(lds + e * SLOT + piece * PIECE), 16, 0, 0);
+        }
+      }
+    }
+    bf16x8 db[2][6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const size_t mo = (size_t)mcl[i] * D;
+      bf16x8 hh[6];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        hh[k] = *(const bf16x8*)(g.xhat + mo + 32 * k + 8 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s1 += a2[2 * k][i][r] + a2[2 * k + 1][i][r];
+          s2 += a2[2 * k][i][r] * (float)hh[k][r] + a2[2 * k + 1][i][r] * (float)hh[k][4 + r];
+        }
+      }
+      const float c1 = group4_sum(s1) * (1.f / 192.f), c2 = group4_sum(s2) * (1.f / 192.f);
+      const float rr = g.rstd[mcl[i]];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        f32x4 xo[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float4 x = *(const float4*)(g.X + mo + tail_col(2 * k + t, 4 * lg));
+          xo[t] = (f32x4){x.x, x.y, x.z, x.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xo[t][r] += rr * (a2[2 * k + t][i][r] - c1 - (float)hh[k][4 * t + r] * c2);
+        }
+        db[i][k] = pack8(xo[0], xo[1]);
+        if (mrow[i] < g.M) {
+          *(float4*)(g.X + mo + tail_col(2 * k, 4 * lg)) = make_float4(xo[0][0], xo[0][1], xo[0][2], xo[0][3]);
+          *(float4*)(g.X + mo + tail_col(2 * k + 1, 4 * lg)) = make_float4(xo[1][0], xo[1][1], xo[1][2], xo[1][3]);
+          *(bf16x8*)(g.xb + mo + 32 * k + 8 * lg) = db[i][k];
+        }
+      }
+    }
+    if (!g.dO) return;
+    // ---- proj dgrad: dO^T[d][row] = WprojT[d][:] . dXb[row][:] ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int e = 0; e < TPROJ; ++e) {
+      const bf16* sb = lds + e * SLOT + lane * 8;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+          const bf16x8 wp = *(const bf16x8*)(sb + (6 * u + ks) * PIECE);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i] = mfma16(wp, db[i][ks], acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a2[4 * e + u][i] = acc[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (mrow[i] < g.M)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) *(bf16x8*)(g.dO + (size_t)mrow[i] * D + 32 * k + 8 * lg) = pack8(a2[2 * k][i], a2[2 * k + 1][i]);
+    return;
+  }
+  if constexpr (TAIL && KIND == 0) {
     // ---- a2 IS the updated residual stream (fp32, nothing staged through bf16): next LayerNorm in registers, 32- / 16-byte stores ----
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -775,7 +858,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
 // Weight stream of one block: chunk c (hidden units 32 c .. 32 c + 31) = 24 pieces of 64 x 16 bytes;
 //   piece 6 t + ks (t = 0, 1; ks = 0..5): lane (l15, lg) = W1f[32 c + 8 (l15 >> 2) + 4 t + (l15 & 3)][32 ks + 8 lg .. +7]
 //   piece 12 + ot  (ot = 0..11):         lane (l15, lg) = W2[16 ot + l15][32 c + 8 lg .. +7]
-struct MlpPrepArgs { const char* base; size_t blk0, stride, off_w1, off_w2, off_out, off_wp; };     // off_wp: proj weight, or NO_WP
+struct MlpPrepArgs { const char* base; size_t blk0, stride, off_w1, off_w2, off_out, off_wp; int bwd; };     // off_wp: proj weight (bwd: its transpose), or NO_WP
 constexpr size_t NO_WP = ~(size_t)0;
 // The stream buffer holds THREE images and the GELU table: the plain one (NCHUNK entries), the SKEWED one of the pipelined forward
 // (PENTRIES entries: entry j = fc1 fragments of chunk j | fc2 fragments of chunk j - PSKEW; the missing halves are zeros) and the
@@ -796,7 +879,22 @@ __global__ __launch_bounds__(256) void mlp_stream_prep_kernel(const MlpPrepArgs 
   const bf16* src = nullptr;
   if (entry >= NCHUNK + PENTRIES) {                       // block-tail image
     const int t = entry - (NCHUNK + PENTRIES);
-    if (a.off_wp != NO_WP) {
+    if (a.off_wp != NO_WP && a.bwd) {
+      // backward block tail: NCHUNK plain entries whose second-GEMM (fc1 dgrad) rows are permuted by tail_col, then TPROJ entries of
+      // WprojT fragments (the proj dgrad behind the norm2 backward)
+      const bf16* wp = (const bf16*)(q + a.off_wp);
+      if (t < NCHUNK) {
+        if (piece < 12) {
+          const int tt = piece / 6, ks = piece - 6 * tt;
+          src = w1 + (size_t)(HC * t + 8 * (l15 >> 2) + 4 * tt + (l15 & 3)) * D + 32 * ks + 8 * lg;
+        } else {
+          src = w2 + (size_t)tail_col(piece - 12, l15) * HID + HC * t + 8 * lg;
+        }
+      } else if (t < NCHUNK + TPROJ) {
+        const int ot = 4 * (t - NCHUNK) + piece / 6, ks = piece % 6;
+        src = wp + (size_t)tail_col(ot, l15) * D + 32 * ks + 8 * lg;
+      }
+    } else if (a.off_wp != NO_WP) {
       if (t < TPROJ) {
         const bf16* wp = (const bf16*)(q + a.off_wp);
         const int ot = 4 * t + piece / 6, ks = piece % 6;
@@ -882,8 +980,8 @@ extern "C" size_t rovit_mlp_stream_bytes(void) { return (size_t)STREAM_ENTRIES *
 
 // (internal) streams of `depth` blocks laid out inside the prepared-weight buffer of rovit_vit_prepare
 int rovit_mlp_stream_prep_blocks(const void* prep_base, size_t blk0, size_t stride, size_t off_w1, size_t off_w2, size_t off_out,
-                                 size_t off_wp, int depth, rovit_stream_t stream) {
-  const MlpPrepArgs a{(const char*)prep_base, blk0, stride, off_w1, off_w2, off_out, off_wp};
+                                 size_t off_wp, int bwd, int depth, rovit_stream_t stream) {
+  const MlpPrepArgs a{(const char*)prep_base, blk0, stride, off_w1, off_w2, off_out, off_wp, bwd};
   hipLaunchKernelGGL(mlp_stream_prep_kernel, dim3((STREAM_ENTRIES * CH_PIECES * 64 + 255) / 256, depth), dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(mlp_gelu_table_kernel, dim3(GT_ENTRIES / 256, depth), dim3(256), 0, (hipStream_t)stream, a);
   ROVIT_CHECK_LAUNCH("mlp_stream_prep_kernel");
@@ -892,21 +990,27 @@ int rovit_mlp_stream_prep_blocks(const void* prep_base, size_t blk0, size_t stri
 
 // w1f: bf16 (768,192) fc1 weight with the LayerNorm affine folded in (rovit_prep_weight's Wf); w2: bf16 (192,768) fc2 weight;
 // wstream: rovit_mlp_stream_bytes() bytes, 16-byte aligned.
-static int mlp_prepare_stream_impl(const void* w1f, const void* w2, const void* wproj, void* wstream, rovit_stream_t stream);
+static int mlp_prepare_stream_impl(const void* w1f, const void* w2, const void* wproj, void* wstream, rovit_stream_t stream, int bwd = 0);
 extern "C" int rovit_mlp_prepare_stream(const void* w1f, const void* w2, void* wstream, rovit_stream_t stream) {
   return mlp_prepare_stream_impl(w1f, w2, nullptr, wstream, stream);
+}
+// the dgrad image with the backward block tail (rovit_block_tail_bwd): w1f := W2T (768,192), w2 := W1T folded (192,768), wprojT = the
+// TRANSPOSED bf16 proj weight (192,192), row d = the weights of attention-output column d
+extern "C" int rovit_mlp_prepare_stream_tail_bwd(const void* w2T, const void* w1T, const void* wprojT, void* wstream, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(wprojT && rovit_aligned16(wprojT), ROVIT_ERR_NULL, "mlp_prepare_stream_tail_bwd: wprojT missing or misaligned");
+  return mlp_prepare_stream_impl(w2T, w1T, wprojT, wstream, stream, 1);
 }
 // ... with the block-tail image too (rovit_block_tail_fwd): wproj = the bf16 attention-output projection weight (192,192)
 extern "C" int rovit_mlp_prepare_stream_tail(const void* w1f, const void* w2, const void* wproj, void* wstream, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(wproj && rovit_aligned16(wproj), ROVIT_ERR_NULL, "mlp_prepare_stream_tail: wproj missing or misaligned");
   return mlp_prepare_stream_impl(w1f, w2, wproj, wstream, stream);
 }
-static int mlp_prepare_stream_impl(const void* w1f, const void* w2, const void* wproj, void* wstream, rovit_stream_t stream) {
+static int mlp_prepare_stream_impl(const void* w1f, const void* w2, const void* wproj, void* wstream, rovit_stream_t stream, int bwd) {
   ROVIT_CHECK_ARG(w1f && w2 && wstream, ROVIT_ERR_NULL, "mlp_prepare_stream: null pointer");
   ROVIT_CHECK_ARG(rovit_aligned16(w1f) && rovit_aligned16(w2) && rovit_aligned16(wstream), ROVIT_ERR_ALIGN, "mlp_prepare_stream: alignment");
   // one "block" whose fields are addressed relative to w1f
   const MlpPrepArgs a{(const char*)w1f, 0, 0, 0, (size_t)((const char*)w2 - (const char*)w1f), (size_t)((char*)wstream - (const char*)w1f),
-                      wproj ? (size_t)((const char*)wproj - (const char*)w1f) : NO_WP};
+                      wproj ? (size_t)((const char*)wproj - (const char*)w1f) : NO_WP, bwd};
   hipLaunchKernelGGL(mlp_stream_prep_kernel, dim3((STREAM_ENTRIES * CH_PIECES * 64 + 255) / 256, 1), dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(mlp_gelu_table_kernel, dim3(GT_ENTRIES / 256, 1), dim3(256), 0, (hipStream_t)stream, a);
   ROVIT_CHECK_LAUNCH("mlp_stream_prep_kernel");
@@ -1023,5 +1127,25 @@ extern "C" int rovit_mlp_fused_bwd(const void* dY, const void* wstream_bwd, cons
                   "mlp_fused_bwd: cannot raise the LDS limit");
   hipLaunchKernelGGL((mlp_fused_kernel<1, 1, 8>), dim3((M + 255) / 256), dim3(512), lds_bytes(1, 8), (hipStream_t)stream, g);
   ROVIT_CHECK_LAUNCH("mlp_fused_kernel (backward)");
+  return ROVIT_OK;
+}
+
+// rovit_mlp_fused_bwd with the norm2 backward in registers (fp32 dxhat2, nothing staged through bf16) and, behind it, the proj dgrad
+// dO (M,192) = dXb Wproj in the same launch (dO NULL: none).  wstream_bwd from rovit_mlp_prepare_stream_tail_bwd.
+extern "C" int rovit_block_tail_bwd(const void* dY, const void* wstream_bwd, const void* dact, void* dpre, const void* xhat2,
+                                    const float* rstd2, float* dX, void* dXb, void* dO, int M, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(dY && wstream_bwd && dact && dpre && xhat2 && rstd2 && dX && dXb, ROVIT_ERR_NULL, "block_tail_bwd: null pointer");
+  ROVIT_CHECK_ARG(M > 0 && (size_t)M * HID * 2 < ((size_t)1 << 31), ROVIT_ERR_SHAPE, "block_tail_bwd: M = %d out of range", M);
+  ROVIT_CHECK_ARG(rovit_aligned16(dY) && rovit_aligned16(wstream_bwd) && rovit_aligned16(dact) && rovit_aligned16(dpre) &&
+                      rovit_aligned16(xhat2) && rovit_aligned16(dX) && rovit_aligned16(dXb) && rovit_aligned16(dO),
+                  ROVIT_ERR_ALIGN, "block_tail_bwd: buffers must be 16-byte aligned");
+  MlpArgs g{};
+  g.xin = (const bf16*)dY; g.act = (bf16*)dpre; g.mul = (const bf16*)dact; g.X = dX; g.dO = (bf16*)dO;
+  g.wstream = (const bf16*)wstream_bwd + (size_t)(NCHUNK + PENTRIES) * CH_ELEMS;      // the backward block-tail image
+  g.xhat = (bf16*)const_cast<void*>(xhat2); g.rstd = const_cast<float*>(rstd2); g.xb = (bf16*)dXb; g.M = M; g.dbg = g_mlp_dbg;
+  ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<1, 1, 8, false, false, true>, lds_bytes(1, 8)), ROVIT_ERR_LAUNCH,
+                  "block_tail_bwd: cannot raise the LDS limit");
+  hipLaunchKernelGGL((mlp_fused_kernel<1, 1, 8, false, false, true>), dim3((M + 255) / 256), dim3(512), lds_bytes(1, 8), (hipStream_t)stream, g);
+  ROVIT_CHECK_LAUNCH("mlp_fused_kernel (backward block tail)");
   return ROVIT_OK;
 }

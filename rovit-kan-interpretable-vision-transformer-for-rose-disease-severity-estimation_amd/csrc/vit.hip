@@ -257,8 +257,8 @@ extern "C" int rovit_vit_prepare(const float* const* params, void* prep, int dep
     descs.push_back({bp[B_FC2W], nullptr, nullptr, nullptr, q + P.wfc2, q + P.wfc2T, nullptr, D, MLP});
   }
   RUN(rovit_prep_weight_batch(descs.data(), (int)descs.size(), stream));
-  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc1, P.wfc2, P.wmlp, P.wproj, depth, stream));     // + proj: the block-tail image
-  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc2T, P.wfc1T, P.wmlpb, ~(size_t)0, depth, stream));     // dgrad chain: (W2T, W1T), no tail image
+  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc1, P.wfc2, P.wmlp, P.wproj, 0, depth, stream));     // + proj: the block-tail image
+  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc2T, P.wfc1T, P.wmlpb, P.wprojT, 1, depth, stream));     // dgrad chain: (W2T, W1T) + WprojT: the backward block-tail image
   return ROVIT_OK;
 }
 
@@ -583,7 +583,16 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
     if (ss && i + 2 < depth && ev_bdone[i + 2] && hipStreamWaitEvent(sA, ev_bdone[i + 2], 0) != hipSuccess) EVFAIL("event wait");
     // A1 + A2 in one launch (mlp_fused.hip): fc2 dgrad x gelu' -> dpre (kept for B2), fc1 dgrad + norm2 backward without
     // re-reading dpre.  ROVIT_MLP_BWD_FUSED=0: the two launches (A/B timing); the gelu'-recompute memory mode keeps them too.
-    if (mlp_one_launch(M)) {
+    // The backward's counterpart of the block tail (rovit_block_tail_bwd: norm2 backward in registers on the fp32 dxhat2 -- 3 000 x
+    // closer to the fp32 reference than the bf16-staged row pass -- and the proj dgrad A3 behind it in the same launch) is OPT-IN:
+    // measured in the step it is SLOWER, 4.94 against 4.85 ms (ROVIT_BLOCK_TAIL_BWD=1; =2, register epilogue only with A3 as its own
+    // launch: 4.94): unlike the forward, where X enters at the top of the launch, its xhat2 / dX loads, the shuffles and the stores all
+    // sit behind the loop with nothing to overlap them, and the LDS-staged pass it replaces was not the bottleneck.
+    static const int tail_bwd = getenv("ROVIT_BLOCK_TAIL_BWD") ? atoi(getenv("ROVIT_BLOCK_TAIL_BWD")) : 0;
+    const bool a3_fused = tail_bwd == 1 && mlp_one_launch(M);
+    if (tail_bwd && mlp_one_launch(M)) {
+      RUN(rovit_block_tail_bwd(xin, q + P.wmlpb, s + L.dact, dp, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmid, a3_fused ? ws + L.dO : nullptr, M, sA));
+    } else if (mlp_one_launch(M)) {
       RUN(rovit_mlp_fused_bwd(xin, q + P.wmlpb, s + L.dact, dp, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmid, M, sA));
     } else {
       if (recompute_gelu())                                                                                            // A1
@@ -602,8 +611,9 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
       RUN(rovit_wgrad(dp, MLP, s + L.xhat2, D, M, MLP, D, L.s_fc1, 0, (float*)(ws + L.slab_fc1), sB));             // B2
       RUN(rovit_wgrad(xmid, D, s + L.o, D, M, D, D, L.s_proj, 0, (float*)(ws + L.slab_proj), sB));                 // B3
     }
-    RUN(rovit_gemm_nt(xmid, D, q + P.wprojT, D, M, D, D, nullptr, EPI_BF16, ws + L.dO, D, nullptr, nullptr, 0, nullptr, 0, nullptr, 0,
-                      sA));                                                                                          // A3
+    if (!a3_fused)
+      RUN(rovit_gemm_nt(xmid, D, q + P.wprojT, D, M, D, D, nullptr, EPI_BF16, ws + L.dO, D, nullptr, nullptr, 0, nullptr, 0, nullptr, 0,
+                        sA));                                                                                        // A3
     RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, dq, batch, T, H, D / H, 0.125f, sA));       // A4
     // qkv dgrad fused with the backward of norm1
     RUN(rovit_gemm_ln_bwd(dq, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), dX, xout, sA));      // A5

@@ -56,6 +56,8 @@ SIGNATURES = {
     'rovit_mlp_fused_fwd': (_i, [_vp] * 9 + [_f, _i, _i, _vp]),
     'rovit_mlp_prepare_stream_tail': (_i, [_vp] * 5),
     'rovit_block_tail_fwd': (_i, [_vp] * 12 + [_f, _i, _i, _vp]),
+    'rovit_mlp_prepare_stream_tail_bwd': (_i, [_vp] * 5),
+    'rovit_block_tail_bwd': (_i, [_vp] * 9 + [_i, _vp]),
     'rovit_mlp_fused_bwd': (_i, [_vp] * 8 + [_i, _vp]),
     'rovit_set_mlp_waves': (_i, [_i]),
     'rovit_set_mlp_debug': (_i, [_i]),

@@ -318,6 +318,60 @@ def test_fused_mlp_backward_equals_the_two_launch_dgrad_chain_and_a_torch_refere
     assert float((dpre1.float() - ref_dpre).abs().max()) < 2e-2 * float(ref_dpre.abs().max())
 
 
+@pytest.mark.parametrize('M', [1, 37, 256, 257, 1000, 197 * 12, 256 * 197])
+def test_block_tail_backward_equals_the_dgrad_launches_and_a_torch_reference(M):
+    """rovit_block_tail_bwd = rovit_mlp_fused_bwd with the norm2 backward in registers (fp32 dxhat2 instead of a bf16-staged one) and the
+    proj dgrad dO = dXb Wproj behind it in the same launch: dpre bit-identical, dX / dXb to the bf16 staging the other path has,
+    dO against rovit_gemm_nt on this launch's own dXb (bit-identical: same MFMA chain) and all of it against fp32 torch."""
+    native = _native()
+    g = torch.Generator(device='cpu').manual_seed(1900 + M)
+    r = lambda *s: torch.randn(*s, generator=g)
+    dY = bf(r(M, 192)).to(dev())
+    w2t = bf(r(768, 192) * 0.05).to(dev())
+    w1t = bf(r(192, 768) * 0.05).to(dev())
+    wpT = bf(r(192, 192) * 0.07).to(dev())             # WprojT: row d = weights of attention-output column d
+    dact = bf(torch.rand(M, 768, generator=g) * 1.2 - 0.1).to(dev())
+    xh = bf(r(M, 192)).to(dev())
+    rstd = (torch.rand(M, generator=g) + 0.5).to(dev())
+    dX0 = r(M, 192).to(dev())
+    p, sp = native.ptr, native.stream_ptr()
+    lib = native.load()
+    dact_c = _chunks(dact)
+    # the existing one-launch dgrad kernel + the proj dgrad GEMM
+    ws0 = torch.empty(lib.rovit_mlp_stream_bytes(), dtype=torch.uint8, device=dev())
+    native.call('rovit_mlp_prepare_stream', p(w2t), p(w1t), p(ws0), sp)
+    dpre0 = torch.empty(M, 768, device=dev(), dtype=torch.bfloat16)
+    dXa, dXba = dX0.clone(), torch.empty(M, 192, device=dev(), dtype=torch.bfloat16)
+    native.call('rovit_mlp_fused_bwd', p(dY), p(ws0), p(dact_c), p(dpre0), p(xh), p(rstd), p(dXa), p(dXba), M, sp)
+    # one launch
+    ws = torch.empty(lib.rovit_mlp_stream_bytes(), dtype=torch.uint8, device=dev())
+    native.call('rovit_mlp_prepare_stream_tail_bwd', p(w2t), p(w1t), p(wpT), p(ws), sp)
+    nanb = lambda *s: torch.full(s, float('nan'), device=dev(), dtype=torch.bfloat16)
+    dpre1, dXb1, dO1, dX1 = nanb(M, 768), nanb(M, 192), nanb(M, 192), dX0.clone()
+    native.call('rovit_block_tail_bwd', p(dY), p(ws), p(dact_c), p(dpre1), p(xh), p(rstd), p(dX1), p(dXb1), p(dO1), M, sp)
+    assert torch.equal(dpre0.view(torch.int16), dpre1.view(torch.int16))
+    assert torch.equal(dXb1.view(torch.int16), bf(dX1).view(torch.int16))
+    dpre_r = _rows(dpre1, M)
+    gq = dpre_r.float() @ w1t.float().t()                               # the second dgrad in fp32 (this launch does not stage it through bf16)
+    h = xh.float()
+    ref = dX0 + rstd[:, None] * (gq - gq.mean(1, keepdim=True) - h * (gq * h).mean(1, keepdim=True))
+    ulp = 2 ** -7 * float(gq.abs().max() * rstd.max())
+    e_new, e_old = float((dX1 - ref).abs().max()), float((dXa - ref).abs().max())
+    print('backward block tail: max |dX - fp32 reference|', e_new, 'staged path', e_old, 'bf16 ulp of the dgrad', ulp)
+    assert e_new < 1e-3 * float(ref.abs().max()) + 0.1 * ulp and e_new <= e_old + 1e-6
+    assert float((dX1 - dXa).abs().max()) < 2 * ulp
+    # proj dgrad: against the library GEMM on the same dXb (same MFMA chain: bit-identical) and against fp32
+    dO_chk = torch.empty(M, 192, device=dev(), dtype=torch.bfloat16)
+    native.call('rovit_gemm_nt', p(dXb1), 192, p(wpT), 192, M, 192, 192, None, 0, p(dO_chk), 192, None, None, 0, None, 0, None, 0, sp)
+    assert torch.equal(dO1.view(torch.int16), dO_chk.view(torch.int16))
+    ref_dO = dXb1.float() @ wpT.float().t()
+    assert float((dO1.float() - ref_dO).abs().max()) < 2 ** -7 * float(ref_dO.abs().max()) + 1e-6
+    # dO = NULL: no proj phase, same dX
+    dX2, dXb2, dpre2 = dX0.clone(), nanb(M, 192), nanb(M, 768)
+    native.call('rovit_block_tail_bwd', p(dY), p(ws), p(dact_c), p(dpre2), p(xh), p(rstd), p(dX2), p(dXb2), None, M, sp)
+    assert torch.equal(dX2, dX1) and torch.equal(dXb2.view(torch.int16), dXb1.view(torch.int16))
+
+
 def test_fused_mlp_backward_is_run_to_run_identical_at_full_size():
     native = _native()
     M = 256 * 197

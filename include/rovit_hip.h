@@ -202,11 +202,15 @@ int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const float* b1,
  * X += fc2(GELU(fc1(xhat2)));  xhat_out / rstd_out = LayerNorm(X) (NULL: none).  o: bf16 (M,192) attention output; wstream from
  * rovit_mlp_prepare_stream_tail (w1f, w2 as rovit_mlp_prepare_stream; wproj = the bf16 (192,192) proj weight); act / dact chunk-major
  * as rovit_mlp_fused_fwd.  The residual stream stays in fp32 registers between the halves (nothing staged through bf16: closer to the
- * fp32 reference than proj + rovit_mlp_fused_fwd as two launches, not bit-identical to them). */
-int rovit_mlp_prepare_stream_tail(const void* w1f, const void* w2, const void* wproj, void* wstream, rovit_stream_t stream);
+ * fp32 reference than proj + rovit_mlp_fused_fwd as two launches, not bit-identical to them).
+ * With wqkv_next (the NEXT block's bf16 qkv weight (576,192), its norm1 affine folded in) given to the preparation and bq_next / qkv_next
+ * given to the launch, the launch also writes that block's qkv projection qkv_next (M,576) = xhat_out Wqkv^T + bq_next: the forward
+ * of a block is then two launches, attention and this one. */
+int rovit_mlp_prepare_stream_tail(const void* w1f, const void* w2, const void* wproj, const void* wqkv_next, void* wstream,
+                                  rovit_stream_t stream);
 int rovit_block_tail_fwd(const void* o, const void* wstream, const float* bp, const float* b1, const float* b2, float* X, void* xhat2,
-                         float* rstd2, void* act, void* dact, void* xhat_out, float* rstd_out, float eps, int M, int act_rows,
-                         rovit_stream_t stream);
+                         float* rstd2, void* act, void* dact, void* xhat_out, float* rstd_out, const float* bq_next, void* qkv_next,
+                         float eps, int M, int act_rows, rovit_stream_t stream);
 /* ... and the backward's counterpart: rovit_mlp_fused_bwd with the norm2 backward in registers and, behind it, the proj dgrad
  * dO (M,192) = dXb Wproj in the same launch (dO NULL: none).  wstream_bwd from rovit_mlp_prepare_stream_tail_bwd(W2T, W1T folded,
  * WprojT = the transposed bf16 proj weight). */

@@ -14,7 +14,7 @@ void rovit_set_error(const char* fmt, ...) {
 
 // 100: round 1.  200: round 2 changed rovit_vit_backward(_notify) (leading `images`) and rovit_joint_loss (float severity targets).
 // 300: round 3 adds the fused MLP entry points and the prepared-weight stream they read (rovit_vit_prep_bytes grew).
-extern "C" int rovit_version(void) { return 302; }
+extern "C" int rovit_version(void) { return 303; }
 extern "C" const char* rovit_last_error_string(void) { return g_err; }
 
 #include <mutex>

@@ -68,7 +68,8 @@ constexpr int PENTRIES = NCHUNK + PSKEW;
 // tile pair (2k, 2k+1) gives a lane EIGHT consecutive columns 32k + 8lg .. +7 of its token row: after norm2 those are, as they
 // stand, the fc1 B fragment of k-step k, and X / xhat leave as 32- / 16-byte runs.
 constexpr int TPROJ = 3;                      // ring entries of the proj weight
-constexpr int TENTRIES = TPROJ + PENTRIES;
+constexpr int TQKV = 9;                       // ring entries of the NEXT block's qkv weight (36 output tiles x 6 k-steps), behind the MLP image
+constexpr int TENTRIES = TPROJ + PENTRIES + TQKV;
 __host__ __device__ constexpr int tail_col(int ot, int row) { return 32 * (ot >> 1) + 8 * (row >> 2) + 4 * (ot & 1) + (row & 3); }
 constexpr int CSTR = 192 + 8;                 // staged output tile [ROWS][CSTR] bf16
 // NW waves per workgroup, 32 rows per wave.  NW = 8: one 256-row workgroup per CU.  NW = 4 (forward only): 128-row workgroups,
@@ -96,6 +97,8 @@ struct MlpArgs {
   int act_rows;           // forward: rows of the whole chunk-major tensors (>= M: a launch may cover a row range of them)
   const float* bp;        // TAIL: (192) proj bias
   bf16* dO;               // backward TAIL: (M,192) gradient w.r.t. the attention output (= dXb Wproj), or NULL
+  const float* bq;        // forward TAIL: (576) folded qkv bias of the NEXT block
+  bf16* qkv;              // forward TAIL: (M,576) the next block's qkv projection of xhat_out, or NULL (no qkv phase)
   bf16* xhat2;            // TAIL: norm2 output (M,192) kept for the backward (NULL: inference)
   float* rstd2;           // TAIL: (M)
   const bf16* gelu_table; // pipelined forward: the 32 KB table behind the two stream images
@@ -136,13 +139,15 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 template <int KIND, int MODE, int NW, bool STAG = false, bool PIPE = false, bool TAIL = false>
 __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) {
   static_assert(!TAIL || PIPE || KIND == 1, "the forward block tail builds on the pipelined forward");
-  constexpr int NBIAS = HID + D + (TAIL ? D : 0);       // floats behind the ring: b1, b2 [, proj bias]
+  constexpr int NBIAS = HID + D + (TAIL ? D + 3 * D : 0);       // floats behind the ring: b1, b2 [, proj bias, next block's qkv bias]
   static_assert(!STAG || (KIND == 0 && NW == 8), "the staggered schedule is the 8-wave forward's");
   static_assert(!PIPE || (KIND == 0 && NW == 8 && !STAG), "the pipelined schedule is the 8-wave forward's");
   constexpr int S = 2 * MODE;                 // stores one wave issues per chunk
   constexpr int ROWS = 32 * NW;               // rows per workgroup: wave w owns the 16-row tiles w and w + NW
   constexpr int PW = CH_PIECES / NW + (KIND ? 2 : 0);   // DMA pieces one wave issues per chunk
   constexpr int SLOT = slot_elems(KIND, NW);
+  constexpr int J0 = (TAIL && !KIND) ? TPROJ : 0;                  // forward block tail: ring entries in front of the MLP image
+  const int NTOT = PENTRIES + J0 + ((TAIL && !KIND && g.qkv) ? TQKV : 0);   // ... and in all (wave-uniform)
   extern __shared__ __attribute__((aligned(16))) bf16 lds[];   // ONE array: ring / staged tile, then the two biases
   float* s_bias = (float*)(lds + region_elems(KIND, NW));       // forward: [768] b1, [192] b2
   const int tid = threadIdx.x, lane = tid & 63;
@@ -173,8 +178,11 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
     }
   };
   if (!KIND && tid < NBIAS / 4) {                 // biases -> LDS (240 / 288 float4)
-    const float4 v = tid < HID / 4 ? ((const float4*)g.b1)[tid] : tid < (HID + D) / 4 ? ((const float4*)g.b2)[tid - HID / 4]
-                                                                                       : ((const float4*)g.bp)[tid - (HID + D) / 4];
+    float4 v;
+    if (tid < HID / 4) v = ((const float4*)g.b1)[tid];
+    else if (tid < (HID + D) / 4) v = ((const float4*)g.b2)[tid - HID / 4];
+    else if (tid < (HID + 2 * D) / 4) v = ((const float4*)g.bp)[tid - (HID + D) / 4];
+    else v = g.bq ? ((const float4*)g.bq)[tid - (HID + 2 * D) / 4] : make_float4(0.f, 0.f, 0.f, 0.f);
     ((float4*)s_bias)[tid] = v;
   }
   bf16x8 xf[2][6];
@@ -191,6 +199,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
   // cblk = bytes from one chunk to the next; rows beyond M get an offset that stays outside num_records for every chunk.
   const unsigned cblk = (unsigned)(KIND ? g.M : g.act_rows) * (HC * 2);
   const int nrec = (int)((size_t)(NCHUNK - 1) * cblk + (size_t)g.M * (HC * 2));
+  __amdgpu_buffer_rsrc_t r_qkv;
+  if (TAIL && !KIND) r_qkv = __builtin_amdgcn_make_buffer_rsrc((void*)g.qkv, 0, g.qkv ? (int)((size_t)g.M * 3 * D * 2) : 0, 0x00020000);
   if (MODE >= 1) r_act = __builtin_amdgcn_make_buffer_rsrc((void*)g.act, 0, nrec, 0x00020000);
   if (MODE == 2) r_dact = __builtin_amdgcn_make_buffer_rsrc((void*)g.dact, 0, nrec, 0x00020000);
   unsigned soff[2];
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
     bf16x8 pk[2] = {};               // bf16(pre-activation) of chunk j - 1: tile i, elements 4 t + r
     bf16x8 avo[2] = {};              // PSKEW = 2: gelu of chunk j - 2
     int slot = 0;
-    constexpr int J0 = TAIL ? TPROJ : 0, NTOT = PENTRIES + J0;      // ring entries in front of the MLP image / in all
+
     // every iteration issues [DMA(J+2): PW] [S stores] (iterations without real stores send theirs out of range: dropped, but
     // counted), so the counted waits are those of the lockstep loop with NTOT entries
     auto top = [&](int J) {
@@ -725,6 +735,52 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
           if (lg == 0) g.rstd[mrow[i]] = rs;
         }
       }
+      if (g.qkv) {                  // the normalised rows as the B fragments of the next block's qkv projection
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          f32x4 lo, hi;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { lo[r] = (a2[2 * k][i][r] - mean) * rs; hi[r] = (a2[2 * k + 1][i][r] - mean) * rs; }
+          xf[i][k] = pack8(lo, hi);
+        }
+      }
+    }
+    if (!g.qkv) return;
+    // ---- the NEXT block's qkv projection (its norm1 affine is folded into the weight): 9 more ring entries of 4 output tiles; the
+    // weight rows are permuted like proj's, so a lane's tile pair is 16 bytes of a qkv row ----
+    if constexpr (PIPE) {
+      int slot = (J0 + PENTRIES) % 3;
+#pragma unroll 1
+      for (int e = 0; e < TQKV; ++e) {
+        const int J = J0 + PENTRIES + e;
+        if (J < NTOT - 1) wait_vm<PW + 2 * S>(); else wait_vm<2 * S>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (J + 2 < NTOT) dma(J + 2, slot == 0 ? 2 : slot - 1);
+        const bf16* sb = lds + slot * SLOT + lane * 8;
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const f32x4 b = *(const f32x4*)(s_bias + HID + 2 * D + 64 * e + tail_col(u, 4 * lg));
+          acc[u][0] = b; acc[u][1] = b;
+#pragma unroll
+          for (int ks = 0; ks < 6; ++ks) {
+            const bf16x8 wq = *(const bf16x8*)(sb + (6 * u + ks) * PIECE);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[u][i] = mfma16(wq, xf[i][ks], acc[u][i]);
+          }
+        }
+        // stores: at least S per iteration (the counted waits assume them); rows beyond M are sent out of range
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const unsigned off = mrow[i] < g.M ? (unsigned)mrow[i] * (3 * D * 2) + (64 * e + 32 * k + 8 * lg) * 2 : 0xFFFFFF00u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, pack8(acc[2 * k][i], acc[2 * k + 1][i])), r_qkv, off, 0, 0);
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        slot = slot == 2 ? 0 : slot + 1;
+      }
     }
     return;
   }
@@ -858,7 +914,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
 // Weight stream of one block: chunk c (hidden units 32 c .. 32 c + 31) = 24 pieces of 64 x 16 bytes;
 //   piece 6 t + ks (t = 0, 1; ks = 0..5): lane (l15, lg) = W1f[32 c + 8 (l15 >> 2) + 4 t + (l15 & 3)][32 ks + 8 lg .. +7]
 //   piece 12 + ot  (ot = 0..11):         lane (l15, lg) = W2[16 ot + l15][32 c + 8 lg .. +7]
-struct MlpPrepArgs { const char* base; size_t blk0, stride, off_w1, off_w2, off_out, off_wp; int bwd; };     // off_wp: proj weight (bwd: its transpose), or NO_WP
+struct MlpPrepArgs { const char* base; size_t blk0, stride, off_w1, off_w2, off_out, off_wp; int bwd; size_t off_wq; int n_next; };   // off_wq: the NEXT block's folded qkv weight (forward tail), or NO_WP     // off_wp: proj weight (bwd: its transpose), or NO_WP
 constexpr size_t NO_WP = ~(size_t)0;
 // The stream buffer holds THREE images and the GELU table: the plain one (NCHUNK entries), the SKEWED one of the pipelined forward
 // (PENTRIES entries: entry j = fc1 fragments of chunk j | fc2 fragments of chunk j - PSKEW; the missing halves are zeros) and the
@@ -899,6 +955,12 @@ __global__ __launch_bounds__(256) void mlp_stream_prep_kernel(const MlpPrepArgs 
         const bf16* wp = (const bf16*)(q + a.off_wp);
         const int ot = 4 * t + piece / 6, ks = piece % 6;
         src = wp + (size_t)tail_col(ot, l15) * D + 32 * ks + 8 * lg;
+      } else if (t >= TPROJ + PENTRIES) {                  // the next block's qkv weight (none behind the last block)
+        if (a.off_wq != NO_WP && (int)blockIdx.y < a.n_next) {             // n_next: blocks (from 0) that have a next block
+          const bf16* wq = (const bf16*)(q + a.off_wq);
+          const int ot = 4 * (t - TPROJ - PENTRIES) + piece / 6, ks = piece % 6;
+          src = wq + (size_t)tail_col(ot, l15) * D + 32 * ks + 8 * lg;
+        }
       } else {
         const int c = t - TPROJ - (piece < 12 ? 0 : PSKEW);
         if (c >= 0 && c < NCHUNK) {
@@ -980,8 +1042,8 @@ extern "C" size_t rovit_mlp_stream_bytes(void) { return (size_t)STREAM_ENTRIES *
 
 // (internal) streams of `depth` blocks laid out inside the prepared-weight buffer of rovit_vit_prepare
 int rovit_mlp_stream_prep_blocks(const void* prep_base, size_t blk0, size_t stride, size_t off_w1, size_t off_w2, size_t off_out,
-                                 size_t off_wp, int bwd, int depth, rovit_stream_t stream) {
-  const MlpPrepArgs a{(const char*)prep_base, blk0, stride, off_w1, off_w2, off_out, off_wp, bwd};
+                                 size_t off_wp, int bwd, size_t off_wq_next, int depth, rovit_stream_t stream) {
+  const MlpPrepArgs a{(const char*)prep_base, blk0, stride, off_w1, off_w2, off_out, off_wp, bwd, off_wq_next, depth - 1};
   hipLaunchKernelGGL(mlp_stream_prep_kernel, dim3((STREAM_ENTRIES * CH_PIECES * 64 + 255) / 256, depth), dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(mlp_gelu_table_kernel, dim3(GT_ENTRIES / 256, depth), dim3(256), 0, (hipStream_t)stream, a);
   ROVIT_CHECK_LAUNCH("mlp_stream_prep_kernel");
@@ -990,7 +1052,8 @@ int rovit_mlp_stream_prep_blocks(const void* prep_base, size_t blk0, size_t stri
 
 // w1f: bf16 (768,192) fc1 weight with the LayerNorm affine folded in (rovit_prep_weight's Wf); w2: bf16 (192,768) fc2 weight;
 // wstream: rovit_mlp_stream_bytes() bytes, 16-byte aligned.
-static int mlp_prepare_stream_impl(const void* w1f, const void* w2, const void* wproj, void* wstream, rovit_stream_t stream, int bwd = 0);
+static int mlp_prepare_stream_impl(const void* w1f, const void* w2, const void* wproj, void* wstream, rovit_stream_t stream, int bwd = 0,
+                                   const void* wqkv_next = nullptr);
 extern "C" int rovit_mlp_prepare_stream(const void* w1f, const void* w2, void* wstream, rovit_stream_t stream) {
   return mlp_prepare_stream_impl(w1f, w2, nullptr, wstream, stream);
 }
@@ -1001,16 +1064,21 @@ extern "C" int rovit_mlp_prepare_stream_tail_bwd(const void* w2T, const void* w1
   return mlp_prepare_stream_impl(w2T, w1T, wprojT, wstream, stream, 1);
 }
 // ... with the block-tail image too (rovit_block_tail_fwd): wproj = the bf16 attention-output projection weight (192,192)
-extern "C" int rovit_mlp_prepare_stream_tail(const void* w1f, const void* w2, const void* wproj, void* wstream, rovit_stream_t stream) {
-  ROVIT_CHECK_ARG(wproj && rovit_aligned16(wproj), ROVIT_ERR_NULL, "mlp_prepare_stream_tail: wproj missing or misaligned");
-  return mlp_prepare_stream_impl(w1f, w2, wproj, wstream, stream);
+// wqkv_next (may be NULL): the bf16 qkv weight (576,192) of the NEXT block with its norm1 affine folded in -- rovit_block_tail_fwd then
+// also writes that block's qkv projection
+extern "C" int rovit_mlp_prepare_stream_tail(const void* w1f, const void* w2, const void* wproj, const void* wqkv_next, void* wstream,
+                                             rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(wproj && rovit_aligned16(wproj) && rovit_aligned16(wqkv_next), ROVIT_ERR_NULL, "mlp_prepare_stream_tail: wproj missing or misaligned");
+  return mlp_prepare_stream_impl(w1f, w2, wproj, wstream, stream, 0, wqkv_next);
 }
-static int mlp_prepare_stream_impl(const void* w1f, const void* w2, const void* wproj, void* wstream, rovit_stream_t stream, int bwd) {
+static int mlp_prepare_stream_impl(const void* w1f, const void* w2, const void* wproj, void* wstream, rovit_stream_t stream, int bwd,
+                                   const void* wqkv_next) {
   ROVIT_CHECK_ARG(w1f && w2 && wstream, ROVIT_ERR_NULL, "mlp_prepare_stream: null pointer");
   ROVIT_CHECK_ARG(rovit_aligned16(w1f) && rovit_aligned16(w2) && rovit_aligned16(wstream), ROVIT_ERR_ALIGN, "mlp_prepare_stream: alignment");
   // one "block" whose fields are addressed relative to w1f
   const MlpPrepArgs a{(const char*)w1f, 0, 0, 0, (size_t)((const char*)w2 - (const char*)w1f), (size_t)((char*)wstream - (const char*)w1f),
-                      wproj ? (size_t)((const char*)wproj - (const char*)w1f) : NO_WP, bwd};
+                      wproj ? (size_t)((const char*)wproj - (const char*)w1f) : NO_WP, bwd,
+                      wqkv_next ? (size_t)((const char*)wqkv_next - (const char*)w1f) : NO_WP, wqkv_next ? 1 : 0};
   hipLaunchKernelGGL(mlp_stream_prep_kernel, dim3((STREAM_ENTRIES * CH_PIECES * 64 + 255) / 256, 1), dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(mlp_gelu_table_kernel, dim3(GT_ENTRIES / 256, 1), dim3(256), 0, (hipStream_t)stream, a);
   ROVIT_CHECK_LAUNCH("mlp_stream_prep_kernel");
@@ -1080,8 +1148,11 @@ extern "C" int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const
 // o: bf16 (M,192) attention output; wstream: rovit_mlp_prepare_stream_tail's buffer; act / dact as rovit_mlp_fused_fwd (chunk-major).
 // The residual stream stays in fp32 registers between the two halves: nothing is staged through bf16, X is read and written once.
 extern "C" int rovit_block_tail_fwd(const void* o, const void* wstream, const float* bp, const float* b1, const float* b2, float* X,
-                                    void* xhat2, float* rstd2, void* act, void* dact, void* xhat_out, float* rstd_out, float eps, int M,
-                                    int act_rows, rovit_stream_t stream) {
+                                    void* xhat2, float* rstd2, void* act, void* dact, void* xhat_out, float* rstd_out, const float* bq_next,
+                                    void* qkv_next, float eps, int M, int act_rows, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(!qkv_next || (bq_next && xhat_out && rovit_aligned16(bq_next) && rovit_aligned16(qkv_next)), ROVIT_ERR_NULL,
+                  "block_tail_fwd: the qkv phase needs bq_next, xhat_out and aligned buffers");
+  ROVIT_CHECK_ARG((size_t)M * 3 * D * 2 < ((size_t)1 << 31), ROVIT_ERR_SHAPE, "block_tail_fwd: M = %d out of range", M);
   ROVIT_CHECK_ARG(o && wstream && bp && b1 && b2 && X, ROVIT_ERR_NULL, "block_tail_fwd: null pointer");
   ROVIT_CHECK_ARG(M > 0 && act_rows >= M && (size_t)act_rows * HID * 2 < ((size_t)1 << 31), ROVIT_ERR_SHAPE,
                   "block_tail_fwd: M = %d, act_rows = %d out of range", M, act_rows);
@@ -1092,10 +1163,10 @@ extern "C" int rovit_block_tail_fwd(const void* o, const void* wstream, const fl
                   ROVIT_ERR_ALIGN, "block_tail_fwd: buffers must be 16-byte aligned");
   MlpArgs g{};
   g.xin = (const bf16*)o; g.b1 = b1; g.b2 = b2; g.bp = bp; g.act = (bf16*)act; g.dact = (bf16*)dact; g.xhat2 = (bf16*)xhat2; g.rstd2 = rstd2;
-  g.X = X; g.xhat = (bf16*)xhat_out; g.rstd = rstd_out; g.eps = eps; g.M = M; g.act_rows = act_rows;
+  g.X = X; g.xhat = (bf16*)xhat_out; g.rstd = rstd_out; g.eps = eps; g.M = M; g.act_rows = act_rows; g.bq = bq_next; g.qkv = (bf16*)qkv_next;
   g.gelu_table = (const bf16*)wstream + (size_t)STREAM_ENTRIES * CH_ELEMS;
   g.wstream = (const bf16*)wstream + (size_t)(NCHUNK + PENTRIES) * CH_ELEMS;          // the block-tail image
-  const size_t lds = lds_bytes(0, 8) + D * sizeof(float) + GT_ENTRIES * 4;
+  const size_t lds = lds_bytes(0, 8) + 4 * D * sizeof(float) + GT_ENTRIES * 4;
   const dim3 grid((M + 255) / 256), block(512);
 #define LAUNCH_TAIL(MD)                                                                                                          \
   do {                                                                                                                           \

@@ -257,8 +257,8 @@ extern "C" int rovit_vit_prepare(const float* const* params, void* prep, int dep
     descs.push_back({bp[B_FC2W], nullptr, nullptr, nullptr, q + P.wfc2, q + P.wfc2T, nullptr, D, MLP});
   }
   RUN(rovit_prep_weight_batch(descs.data(), (int)descs.size(), stream));
-  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc1, P.wfc2, P.wmlp, P.wproj, 0, depth, stream));     // + proj: the block-tail image
-  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc2T, P.wfc1T, P.wmlpb, P.wprojT, 1, depth, stream));     // dgrad chain: (W2T, W1T) + WprojT: the backward block-tail image
+  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc1, P.wfc2, P.wmlp, P.wproj, 0, P.blk_stride + P.wqkv, depth, stream));     // + proj and the NEXT block's qkv: the block-tail image
+  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc2T, P.wfc1T, P.wmlpb, P.wprojT, 1, ~(size_t)0, depth, stream));     // dgrad chain: (W2T, W1T) + WprojT: the backward block-tail image
   return ROVIT_OK;
 }
 
@@ -295,6 +295,7 @@ int vit_forward_impl(const float* images, const float* const* params, const void
   }
   struct BudgetReset { bool on; ~BudgetReset() { if (on) rovit_set_cu_budget(256); } } budget_reset{ss != nullptr};
 #define EACH_HALF for (int hh = 0; hh < nh; ++hh)
+  bool qkv_done = false;              // the previous block's tail launch has already written this block's qkv projection
   for (int i = 0; i < depth; ++i) {
     const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
     const char* q = pb + P.blk0 + (size_t)i * P.blk_stride;
@@ -318,11 +319,12 @@ int vit_forward_impl(const float* images, const float* const* params, const void
         const Half& h = halves[hh];
         RUN(rovit_layernorm_fwd(X + (size_t)h.b0 * T * D, ROWS(s + L.xhat1, D, 2), (float*)ROWS(s + L.rstd1, 1, 4), h.nb * T, D, eps, h.st));
       }
-      for (int hh = h_lo; hh < h_hi; ++hh) {
+      if (!qkv_done) for (int hh = h_lo; hh < h_hi; ++hh) {
         const Half& h = halves[hh];
         RUN(rovit_gemm_nt(ROWS(s + L.xhat1, D, 2), D, q + P.wqkv, D, h.nb * T, 3 * D, D, (const float*)(q + P.bqkv), EPI_BF16,
                           ROWS(s + L.qkv, 3 * D, 2), 3 * D, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, h.st));
       }
+      qkv_done = false;
       for (int hh = h_lo; hh < h_hi; ++hh) {
         const Half& h = halves[hh];
         RUN(rovit_attention_fwd(ROWS(s + L.qkv, 3 * D, 2), ROWS(s + L.o, D, 2), (float*)(s + L.lse) + (size_t)h.b0 * H * T, h.nb, T, H, D / H,
@@ -342,13 +344,19 @@ int vit_forward_impl(const float* images, const float* const* params, const void
     static const bool block_tail = !(getenv("ROVIT_BLOCK_TAIL") && getenv("ROVIT_BLOCK_TAIL")[0] == '0');
     if (block_tail && !cls_only && mlp_one_launch((long)batch * T)) {
       char* sn = ws + L.blk0 + (size_t)(i + 1) * L.blk_stride;            // next block's saved-activation area
+      static const bool tail_qkv_env = !(getenv("ROVIT_BLOCK_TAIL_QKV") && getenv("ROVIT_BLOCK_TAIL_QKV")[0] == '0');
+      const bool tail_qkv = tail_qkv_env;
+      qkv_done = tail_qkv;                                                // block i + 1 finds its qkv projection written
       EACH_HALF {
         const Half& h = halves[hh];
         float* Xh = X + (size_t)h.b0 * T * D;
+        // ... and the NEXT block's qkv projection behind its norm1 (ROVIT_BLOCK_TAIL_QKV=0: that stays a launch of the next block)
         RUN(rovit_block_tail_fwd(ROWS(s + L.o, D, 2), q + P.wmlp, bp[B_PROJB], (const float*)(q + P.bfc1), bp[B_FC2B], Xh,
                                  training ? ROWS(s + L.xhat2, D, 2) : nullptr, training ? (float*)ROWS(s + L.rstd2, 1, 4) : nullptr,
                                  training ? ROWS(s + L.act, 32, 2) : nullptr, training ? ROWS(s + L.dact, 32, 2) : nullptr,
-                                 ROWS(sn + L.xhat1, D, 2), (float*)ROWS(sn + L.rstd1, 1, 4), eps, h.nb * T, batch * T, h.st));
+                                 ROWS(sn + L.xhat1, D, 2), (float*)ROWS(sn + L.rstd1, 1, 4),
+                                 tail_qkv ? (const float*)(q + P.blk_stride + P.bqkv) : nullptr, tail_qkv ? ROWS(sn + L.qkv, 3 * D, 2) : nullptr,
+                                 eps, h.nb * T, batch * T, h.st));
       }
       continue;
     }

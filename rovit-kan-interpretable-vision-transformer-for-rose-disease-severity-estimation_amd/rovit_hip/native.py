@@ -15,7 +15,7 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get('ROVIT_HIP_LIB') or os.path.join(_PKG_ROOT, 'lib', 'librovit_hip.so')   # env override: developer A/B builds
 
 _lib: Optional[C.CDLL] = None
-ABI_VERSION = 302          # rovit_version() this binding matches (csrc/api.hip)
+ABI_VERSION = 303          # rovit_version() this binding matches (csrc/api.hip)
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -54,8 +54,8 @@ SIGNATURES = {
     'rovit_mlp_stream_bytes': (_sz, []),
     'rovit_mlp_prepare_stream': (_i, [_vp, _vp, _vp, _vp]),
     'rovit_mlp_fused_fwd': (_i, [_vp] * 9 + [_f, _i, _i, _vp]),
-    'rovit_mlp_prepare_stream_tail': (_i, [_vp] * 5),
-    'rovit_block_tail_fwd': (_i, [_vp] * 12 + [_f, _i, _i, _vp]),
+    'rovit_mlp_prepare_stream_tail': (_i, [_vp] * 6),
+    'rovit_block_tail_fwd': (_i, [_vp] * 14 + [_f, _i, _i, _vp]),
     'rovit_mlp_prepare_stream_tail_bwd': (_i, [_vp] * 5),
     'rovit_block_tail_bwd': (_i, [_vp] * 9 + [_i, _vp]),
     'rovit_mlp_fused_bwd': (_i, [_vp] * 8 + [_i, _vp]),

@@ -165,14 +165,27 @@ def test_block_tail_equals_proj_plus_mlp_half_and_a_torch_reference(M, train):
     native.call('rovit_gemm_resid_ln', p(o), 192, p(wp), 192, M, 192, p(bp_), p(Xa), p(xh2a), p(r2a), 1e-6, sp)
     acta, dacta, Xa2, xh1a, r1a = _fused(native, xh2a, w1, w2, b1, b2, Xa)
     # one launch
+    nanb2 = lambda *s: torch.full(s, float('nan'), device=dev(), dtype=torch.bfloat16)
     ws = torch.empty(lib.rovit_mlp_stream_bytes(), dtype=torch.uint8, device=dev())
-    native.call('rovit_mlp_prepare_stream_tail', p(w1), p(w2), p(wp), p(ws), sp)
-    nanb = lambda *s: torch.full(s, float('nan'), device=dev(), dtype=torch.bfloat16)
+    wq = bf(r(576, 192) * 0.07).to(dev())              # the NEXT block's qkv weight (norm1 affine folded in) and bias
+    bq = (r(576) * 0.2).to(dev())
+    native.call('rovit_mlp_prepare_stream_tail', p(w1), p(w2), p(wp), p(wq), p(ws), sp)
+    qkv = nanb2(M, 576)
+    nanb = nanb2
     X = X0.clone()
     xh2, r2 = (nanb(M, 192), torch.full((M,), float('nan'), device=dev())) if train else (None, None)
     act, dact = (nanb(M, 768), nanb(M, 768)) if train else (None, None)
     xh1, r1 = nanb(M, 192), torch.full((M,), float('nan'), device=dev())
-    native.call('rovit_block_tail_fwd', p(o), p(ws), p(bp_), p(b1), p(b2), p(X), p(xh2), p(r2), p(act), p(dact), p(xh1), p(r1), 1e-6, M, M, sp)
+    native.call('rovit_block_tail_fwd', p(o), p(ws), p(bp_), p(b1), p(b2), p(X), p(xh2), p(r2), p(act), p(dact), p(xh1), p(r1), p(bq), p(qkv),
+                1e-6, M, M, sp)
+    # the next block's qkv projection of the normalised rows: bit-identical to the library GEMM on this launch's own xhat_out
+    qkv_chk = torch.empty(M, 576, device=dev(), dtype=torch.bfloat16)
+    native.call('rovit_gemm_nt', p(xh1), 192, p(wq), 192, M, 576, 192, p(bq), 0, p(qkv_chk), 576, None, None, 0, None, 0, None, 0, sp)
+    assert torch.equal(qkv.view(torch.int16), qkv_chk.view(torch.int16))
+    # and without the qkv phase (qkv_next = NULL) everything else is unchanged
+    Xn, xh1n, r1n = X0.clone(), nanb(M, 192), torch.full((M,), float('nan'), device=dev())
+    native.call('rovit_block_tail_fwd', p(o), p(ws), p(bp_), p(b1), p(b2), p(Xn), None, None, None, None, p(xh1n), p(r1n), None, None, 1e-6, M, M, sp)
+    assert torch.equal(Xn, X) and torch.equal(xh1n.view(torch.int16), xh1.view(torch.int16)) and torch.equal(r1n, r1)
     # fp32 reference on the same bf16 operands (xhat2 rounded to bf16 where the kernels round it)
     Xm = X0 + o.float() @ wp.float().t() + bp_
     ln = lambda t: torch.nn.functional.layer_norm(t, (192,), eps=1e-6)

@@ -197,6 +197,28 @@ def mlp_roofline(dev):
     res['fused_fwd_inference'] = _entry(dev, lambda: lib.rovit_mlp_fused_fwd(p(xhat2), p(ws), p(b1), p(b2), None, None, p(X), p(xhat), p(rstd), 1e-6, M, M, sp),
                                         2.0 * M * 192 * 2 + 8.0 * M * 192 + 4.0 * M + wbytes, 4.0 * M * 768 * 192,
                                         'mlp_fused_kernel<0,0,8,false,true>: the same, nothing kept (inference)', 'mlp_fused_fwd_inference')
+    # the step's forward kernel since late round 3: everything of a block behind the attention + the next block's qkv projection
+    o = torch.randn(M, 192, device=dev).to(bf)
+    wp = (torch.randn(192, 192, device=dev) * 0.07).to(bf)
+    wq = (torch.randn(576, 192, device=dev) * 0.07).to(bf)
+    bp_, bq = torch.randn(192, device=dev) * 0.2, torch.randn(576, device=dev) * 0.2
+    wst = torch.empty_like(ws)
+    native.call('rovit_mlp_prepare_stream_tail', p(w1), p(w2), p(wp), p(wq), p(wst), sp)
+    xh2, r2 = torch.empty(M, 192, device=dev, dtype=bf), torch.empty(M, device=dev)
+    qkv = torch.empty(M, 576, device=dev, dtype=bf)
+    tail_w = wbytes + 2.0 * 192 * 192 + 2.0 * 576 * 192
+    tail_flops = 4.0 * M * 768 * 192 + 2.0 * M * 192 * 192 + 2.0 * M * 192 * 576
+    res['block_tail_train'] = _entry(
+        dev, lambda: lib.rovit_block_tail_fwd(p(o), p(wst), p(bp_), p(b1), p(b2), p(X), p(xh2), p(r2), p(act), p(dact), p(xhat), p(rstd), p(bq), p(qkv),
+                                              1e-6, M, M, sp),
+        2.0 * M * 192 * 3 + 8.0 * M * 192 + 2.0 * M * 768 * 2 + 2.0 * M * 576 + 8.0 * M + tail_w, tail_flops,
+        'mlp_fused_kernel<0,2,8,false,true,true> (block tail): proj + residual + norm2 + fc1 + GELU + fc2 + residual + next norm1 + next qkv, M=50432',
+        'block_tail_train')
+    res['block_tail_inference'] = _entry(
+        dev, lambda: lib.rovit_block_tail_fwd(p(o), p(wst), p(bp_), p(b1), p(b2), p(X), None, None, None, None, p(xhat), p(rstd), p(bq), p(qkv),
+                                              1e-6, M, M, sp),
+        2.0 * M * 192 * 2 + 8.0 * M * 192 + 2.0 * M * 576 + 4.0 * M + tail_w, tail_flops,
+        'mlp_fused_kernel<0,0,8,false,true,true>: the same, nothing kept (inference)', 'block_tail_inference')
     dact.uniform_(0, 1)
     res['fused_bwd'] = _entry(dev, lambda: lib.rovit_mlp_fused_bwd(p(dY), p(wsb), p(dact), p(dpre), p(xhat2), p(rstd), p(dX), p(dXb), M, sp),
                               2.0 * M * 192 * 3 + 2.0 * M * 768 * 2 + 8.0 * M * 192 + 4.0 * M + wbytes, 4.0 * M * 768 * 192,

@@ -215,6 +215,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
       if constexpr (TAIL && KIND == 0) {        // the residual stream itself, in the (permuted) accumulator layout: everything is accumulated onto it
         const float4 x = *(const float4*)(g.X + (size_t)mcl[i] * D + tail_col(ot, 4 * lg));
         a2[ot][i] = (f32x4){x.x, x.y, x.z, x.w};
+      } else if constexpr (TAIL && KIND == 1) {  // backward: dX itself (scaled below), so that nothing but xhat2 is loaded behind the loop
+        const float4 x = *(const float4*)(g.X + (size_t)mcl[i] * D + tail_col(ot, 4 * lg));
+        a2[ot][i] = (f32x4){x.x, x.y, x.z, x.w};
       } else {
         a2[ot][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
@@ -232,6 +235,33 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
   dma(0, 0);
   dma(1, 1);
 
+  // Backward block tail: the norm2 backward dX += rstd (g - mean(g) - h mean(g h)) is LINEAR in g = dxhat2, so the accumulators start
+  // as A0 = dX / rstd and the fc1-dgrad chain adds g on top; behind the loop dX_out = rstd (A - c1 - h c2) with
+  // c1 = mean(A) - mean(dX) / rstd, c2 = mean(A h) - mean(dX h) / rstd: dX is read HERE, at the top of the launch, not behind the loop.
+  float bm1[2] = {0.f, 0.f}, bm2[2] = {0.f, 0.f}, binv[2] = {1.f, 1.f};
+  if constexpr (TAIL && KIND == 1) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const size_t mo = (size_t)mcl[i] * D;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const bf16x8 h = *(const bf16x8*)(g.xhat + mo + 32 * k + 8 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s1 += a2[2 * k][i][r] + a2[2 * k + 1][i][r];
+          s2 += a2[2 * k][i][r] * (float)h[r] + a2[2 * k + 1][i][r] * (float)h[4 + r];
+        }
+      }
+      binv[i] = 1.f / g.rstd[mcl[i]];
+      bm1[i] = group4_sum(s1) * (1.f / 192.f) * binv[i];
+      bm2[i] = group4_sum(s2) * (1.f / 192.f) * binv[i];
+#pragma unroll
+      for (int ot = 0; ot < 12; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a2[ot][i][r] *= binv[i];
+    }
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // bias ds_writes retired before the first barrier
   if constexpr (STAG) {
     static_assert(4 * CH_ELEMS <= region_elems(0, 8), "four ring slots must fit under the staged output tile");
@@ -650,18 +680,15 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
           s2 += a2[2 * k][i][r] * (float)hh[k][r] + a2[2 * k + 1][i][r] * (float)hh[k][4 + r];
         }
       }
-      const float c1 = group4_sum(s1) * (1.f / 192.f), c2 = group4_sum(s2) * (1.f / 192.f);
-      const float rr = g.rstd[mcl[i]];
+      const float c1 = group4_sum(s1) * (1.f / 192.f) - bm1[i], c2 = group4_sum(s2) * (1.f / 192.f) - bm2[i];
+      const float rr = 1.f / binv[i];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         f32x4 xo[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const float4 x = *(const float4*)(g.X + mo + tail_col(2 * k + t, 4 * lg));
-          xo[t] = (f32x4){x.x, x.y, x.z, x.w};
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) xo[t][r] += rr * (a2[2 * k + t][i][r] - c1 - (float)hh[k][4 * t + r] * c2);
-        }
+          for (int r = 0; r < 4; ++r) xo[t][r] = rr * (a2[2 * k + t][i][r] - c1 - (float)hh[k][4 * t + r] * c2);
         db[i][k] = pack8(xo[0], xo[1]);
         if (mrow[i] < g.M) {
           *(float4*)(g.X + mo + tail_col(2 * k, 4 * lg)) = make_float4(xo[0][0], xo[0][1], xo[0][2], xo[0][3]);

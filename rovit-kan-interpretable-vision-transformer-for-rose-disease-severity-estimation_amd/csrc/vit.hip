@@ -593,9 +593,10 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
     // re-reading dpre.  ROVIT_MLP_BWD_FUSED=0: the two launches (A/B timing); the gelu'-recompute memory mode keeps them too.
     // The backward's counterpart of the block tail (rovit_block_tail_bwd: norm2 backward in registers on the fp32 dxhat2 -- 3 000 x
     // closer to the fp32 reference than the bf16-staged row pass -- and the proj dgrad A3 behind it in the same launch) is OPT-IN:
-    // measured in the step it is SLOWER, 4.94 against 4.85 ms (ROVIT_BLOCK_TAIL_BWD=1; =2, register epilogue only with A3 as its own
-    // launch: 4.94): unlike the forward, where X enters at the top of the launch, its xhat2 / dX loads, the shuffles and the stores all
-    // sit behind the loop with nothing to overlap them, and the LDS-staged pass it replaces was not the bottleneck.
+    // measured in the step it is SLOWER, 4.87 against 4.78 ms (ROVIT_BLOCK_TAIL_BWD=1; =2, register epilogue only with A3 as its own
+    // launch: 4.87) -- even with dX entering at the top of the launch (the norm2 backward is linear in dxhat2: the accumulators start as
+    // dX / rstd2); what stays behind the loop are the xhat2 loads, the shuffles and 16-byte-per-lane stores that split every 128-byte line
+    // over two instructions, where the LDS-staged pass writes whole rows.
     static const int tail_bwd = getenv("ROVIT_BLOCK_TAIL_BWD") ? atoi(getenv("ROVIT_BLOCK_TAIL_BWD")) : 0;
     const bool a3_fused = tail_bwd == 1 && mlp_one_launch(M);
     if (tail_bwd && mlp_one_launch(M)) {

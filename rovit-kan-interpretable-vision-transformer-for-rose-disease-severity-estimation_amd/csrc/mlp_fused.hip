@@ -1072,7 +1072,7 @@ int rovit_mlp_stream_prep_blocks(const void* prep_base, size_t blk0, size_t stri
                                  size_t off_wp, int bwd, size_t off_wq_next, int depth, rovit_stream_t stream) {
   const MlpPrepArgs a{(const char*)prep_base, blk0, stride, off_w1, off_w2, off_out, off_wp, bwd, off_wq_next, depth - 1};
   hipLaunchKernelGGL(mlp_stream_prep_kernel, dim3((STREAM_ENTRIES * CH_PIECES * 64 + 255) / 256, depth), dim3(256), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(mlp_gelu_table_kernel, dim3(GT_ENTRIES / 256, depth), dim3(256), 0, (hipStream_t)stream, a);
+  if (!bwd) hipLaunchKernelGGL(mlp_gelu_table_kernel, dim3(GT_ENTRIES / 256, depth), dim3(256), 0, (hipStream_t)stream, a);   // only the forward looks GELU up
   ROVIT_CHECK_LAUNCH("mlp_stream_prep_kernel");
   return ROVIT_OK;
 }

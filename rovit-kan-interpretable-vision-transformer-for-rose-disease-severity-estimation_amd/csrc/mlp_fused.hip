@@ -95,6 +95,7 @@ struct MlpArgs {
   bf16* dact;             // forward gelu'(pre) (MODE == 2), chunk-major
   const bf16* mul;        // backward gelu'(pre), chunk-major [24][M][32]
   int act_rows;           // forward: rows of the whole chunk-major tensors (>= M: a launch may cover a row range of them)
+  int rpw;                // token rows a workgroup takes (<= 32 NW; fewer = more workgroups, the surplus row tiles idle)
   const float* bp;        // TAIL: (192) proj bias
   bf16* dO;               // backward TAIL: (M,192) gradient w.r.t. the attention output (= dXb Wproj), or NULL
   const float* bq;        // forward TAIL: (576) folded qkv bias of the NEXT block
@@ -153,13 +154,14 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
-  const int r0 = blockIdx.x * ROWS;
+  const int r0 = blockIdx.x * g.rpw;
 
   // this wave's rows: tile i holds rows r0 + 16 (w + NW i) + l15 (clamped for the loads; stores are bounds-checked)
   int mrow[2], mcl[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    mrow[i] = r0 + 16 * NW * i + 16 * w + l15;
+    const int local = 16 * NW * i + 16 * w + l15;
+    mrow[i] = local < g.rpw ? r0 + local : 0x3FFFFFFF;      // rows this workgroup does not own count as beyond M
     mcl[i] = mrow[i] < g.M ? mrow[i] : g.M - 1;
   }
   auto dma = [&](int chunk, int slot) {
@@ -824,6 +826,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
   constexpr int RP = 4 * NW;
   const int c16 = tid & 15, prow = tid >> 4;
   auto crow = [&](int pass) -> int { const int m = r0 + pass * RP + prow; return m < g.M ? m : g.M - 1; };
+  auto owned = [&](int row, int m) -> bool { return row < g.rpw && m < g.M; };
   float4 xa[4][3], xb[4][3];
   bf16x4 ha[4][3], hb[4][3];       // backward: xhat2 rows
   float ra[4], rb[4];              // backward: rstd2
@@ -889,7 +892,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
         f32x4 t = {x.x, x.y, x.z, x.w};
         bq[i] = pack4(t);
       }
-      if (m < g.M) {
+      if (owned(row, m)) {
         bf16x4* bp = (bf16x4*)(g.xb + (size_t)m * D);
 #pragma unroll
         for (int i = 0; i < 3; ++i) xp[16 * i + c16] = xs[i];
@@ -919,7 +922,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
         f32x4 t = {v[4 * i] * r, v[4 * i + 1] * r, v[4 * i + 2] * r, v[4 * i + 3] * r};
         hq[i] = pack4(t);
       }
-      if (m < g.M) {
+      if (owned(row, m)) {
         bf16x4* hp = (bf16x4*)(g.xhat + (size_t)m * D);
 #pragma unroll
         for (int i = 0; i < 3; ++i) xp[16 * i + c16] = xs[i];
@@ -927,7 +930,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
         for (int i = 0; i < 3; ++i) hp[16 * i + c16] = hq[i];
         if (c16 == 0) g.rstd[m] = r;
       }
-    } else if (m < g.M) {
+    } else if (owned(row, m)) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) xp[16 * i + c16] = xs[i];
     }
@@ -1063,6 +1066,12 @@ extern "C" int rovit_set_mlp_waves(int nw) {
 }
 
 static int g_mlp_dbg = 0;
+// token rows per workgroup of the 8-wave kernels (developer knob ROVIT_MLP_RPW; 256 = every row tile used)
+// 0 (default) = by size: a launch of the 8-wave kernels lasts as long as ONE workgroup (197 workgroups of 256 rows at batch 256 run side
+// by side on 256 CUs), so while everything fits one round, 240 rows per workgroup (211 workgroups, one idle row tile each) shorten it:
+// step 4.76 -> 4.69 ms, batch-256 inference 1.30 -> 1.28 ms; from two rounds on (batch 512: 2.26 -> 2.33 ms) full workgroups win.
+static int g_mlp_rpw = [] { const char* e = getenv("ROVIT_MLP_RPW"); const int v = e ? atoi(e) : 0; return (v >= 16 && v <= 256) ? v : 0; }();
+static int mlp_rpw(long total_rows) { return g_mlp_rpw ? g_mlp_rpw : ((total_rows + 239) / 240 <= 256 ? 240 : 256); }
 extern "C" int rovit_set_mlp_debug(int bits) { g_mlp_dbg = bits; return ROVIT_OK; }
 
 extern "C" size_t rovit_mlp_stream_bytes(void) { return (size_t)STREAM_ENTRIES * CH_ELEMS * sizeof(bf16) + GT_ENTRIES * sizeof(unsigned); }
@@ -1131,7 +1140,8 @@ extern "C" int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const
   g.X = X; g.xhat = (bf16*)xhat_out; g.rstd = rstd_out; g.eps = eps; g.M = M; g.act_rows = act_rows; g.dbg = g_mlp_dbg;
   hipStream_t st = (hipStream_t)stream;
   const int nw = g_mlp_waves;
-  const dim3 grid((M + 32 * nw - 1) / (32 * nw)), block(64 * nw);
+  g.rpw = nw == 8 ? mlp_rpw(act_rows) : 32 * nw;
+  const dim3 grid((M + g.rpw - 1) / g.rpw), block(64 * nw);
 #define LAUNCH_MODE(MD, NWV)                                                                                                     \
   do {                                                                                                                           \
     ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<0, MD, NWV>, lds_bytes(0, NWV)), ROVIT_ERR_LAUNCH,           \
@@ -1194,7 +1204,8 @@ extern "C" int rovit_block_tail_fwd(const void* o, const void* wstream, const fl
   g.gelu_table = (const bf16*)wstream + (size_t)STREAM_ENTRIES * CH_ELEMS;
   g.wstream = (const bf16*)wstream + (size_t)(NCHUNK + PENTRIES) * CH_ELEMS;          // the block-tail image
   const size_t lds = lds_bytes(0, 8) + 4 * D * sizeof(float) + GT_ENTRIES * 4;
-  const dim3 grid((M + 255) / 256), block(512);
+  g.rpw = mlp_rpw(act_rows);
+  const dim3 grid((M + g.rpw - 1) / g.rpw), block(512);
 #define LAUNCH_TAIL(MD)                                                                                                          \
   do {                                                                                                                           \
     ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<0, MD, 8, false, true, true>, lds), ROVIT_ERR_LAUNCH,        \
@@ -1223,7 +1234,8 @@ extern "C" int rovit_mlp_fused_bwd(const void* dY, const void* wstream_bwd, cons
   g.xhat = (bf16*)const_cast<void*>(xhat2); g.rstd = const_cast<float*>(rstd2); g.xb = (bf16*)dXb; g.M = M; g.dbg = g_mlp_dbg;
   ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<1, 1, 8>, lds_bytes(1, 8)), ROVIT_ERR_LAUNCH,
                   "mlp_fused_bwd: cannot raise the LDS limit");
-  hipLaunchKernelGGL((mlp_fused_kernel<1, 1, 8>), dim3((M + 255) / 256), dim3(512), lds_bytes(1, 8), (hipStream_t)stream, g);
+  g.rpw = mlp_rpw(M);
+  hipLaunchKernelGGL((mlp_fused_kernel<1, 1, 8>), dim3((M + g.rpw - 1) / g.rpw), dim3(512), lds_bytes(1, 8), (hipStream_t)stream, g);
   ROVIT_CHECK_LAUNCH("mlp_fused_kernel (backward)");
   return ROVIT_OK;
 }
@@ -1243,7 +1255,8 @@ extern "C" int rovit_block_tail_bwd(const void* dY, const void* wstream_bwd, con
   g.xhat = (bf16*)const_cast<void*>(xhat2); g.rstd = const_cast<float*>(rstd2); g.xb = (bf16*)dXb; g.M = M; g.dbg = g_mlp_dbg;
   ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<1, 1, 8, false, false, true>, lds_bytes(1, 8)), ROVIT_ERR_LAUNCH,
                   "block_tail_bwd: cannot raise the LDS limit");
-  hipLaunchKernelGGL((mlp_fused_kernel<1, 1, 8, false, false, true>), dim3((M + 255) / 256), dim3(512), lds_bytes(1, 8), (hipStream_t)stream, g);
+  g.rpw = mlp_rpw(M);
+  hipLaunchKernelGGL((mlp_fused_kernel<1, 1, 8, false, false, true>), dim3((M + g.rpw - 1) / g.rpw), dim3(512), lds_bytes(1, 8), (hipStream_t)stream, g);
   ROVIT_CHECK_LAUNCH("mlp_fused_kernel (backward block tail)");
   return ROVIT_OK;
 }

@@ -233,7 +233,7 @@ extern "C" int rovit_vit_workspace_field(int batch, int depth, int field, int bl
     case ROVIT_WS_RSTD2: *offset = blk + L.rstd2; *bytes = M * 4; break;
     case ROVIT_WS_ACT: *offset = blk + L.act; *bytes = M * MLP * 2; break;
     // the last block's backward (CLS rows only behind the attention) uses buffer 0, the others their parity's
-    case ROVIT_WS_DQKV: *offset = L.dqkv[block == depth - 1 ? 0 : (block & 1)]; *bytes = M * 3 * D * 2; break;
+    case ROVIT_WS_DQKV: *offset = L.dqkv[block & 1]; *bytes = M * 3 * D * 2; break;
     default: rovit_set_error("vit_workspace_field: unknown field %d", field); return ROVIT_ERR_SHAPE;
   }
   return ROVIT_OK;
@@ -482,7 +482,7 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
   hipEvent_t* ev_bdone = ss ? ss->ev_bdone : no_events;
   int pending = -1;                                   // block whose B4/B5 have not been issued yet
 #define EVFAIL(what) do { rovit_set_error("vit_backward: " what " failed"); return ROVIT_ERR_LAUNCH; } while (0)
-  auto reduce_block = [&](int i, bool cls_only, rovit_stream_t st) -> int {
+  auto reduce_block = [&](int i, bool cls_only, rovit_stream_t st, int n = 4) -> int {      // n = 3: without the qkv weight
     const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
     float* const* bg = grads + P_BLOCK0 + B_COUNT * i;
     const int s_fc2 = cls_only ? L.s_fc2c : L.s_fc2, s_fc1 = cls_only ? L.s_fc1c : L.s_fc1, s_proj = cls_only ? L.s_projc : L.s_proj;
@@ -493,7 +493,7 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
         {(const float*)(ws + L.slab_proj), s_proj, D, D, nullptr, nullptr, nullptr, bg[B_PROJW], bg[B_PROJB], nullptr, nullptr, nullptr},
         {(const float*)(ws + L.slab_qkv), L.s_qkv, 3 * D, D, bp[B_N1W], bp[B_N1B], bp[B_QKVW], bg[B_QKVW], bg[B_QKVB], bg[B_N1W], bg[B_N1B],
          (float*)(ws + L.gscr2)}};
-    return rovit_wgrad_reduce_batch(rd, 4, st);
+    return rovit_wgrad_reduce_batch(rd, n, st);
   };
   // Weight gradients of the two-stream schedule: ONE launch per block carries the qkv gradient of the previous block
   // (`pending`, whose dqkv became final with its A5) together with fc2 / fc1 / proj of block i -- 12 output tiles (192 x 192) per
@@ -561,7 +561,7 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
       // small and serial: everything on stream A; the attention-half gradient is updated in place in xin (CLS rows)
       const int Mr = batch, rs = T;
       char* dp = ws + L.dpre[0];
-      char* dq = ws + L.dqkv[0];
+      char* dq = ws + L.dqkv[i & 1];
       if (recompute_gelu())
         RUN(rovit_gemm_mlp_bwd(xin, D * rs, s + L.xhat2, D * rs, q + P.wfc2T, q + P.wfc1, (const float*)(q + P.bfc1), Mr, dp, MLP * rs, stream));
       else
@@ -580,8 +580,16 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
       RUN(rovit_wgrad(xin, D * rs, s + L.o, D * rs, Mr, D, D, L.s_projc, 0, (float*)(ws + L.slab_proj), stream));
       RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, dq, batch, T, H, D / H, 0.125f, stream));
       RUN(rovit_gemm_ln_bwd(dq, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), dX, xout, stream));
-      RUN(rovit_wgrad(dq, 3 * D, s + L.xhat1, D, M, 3 * D, D, L.s_qkv, 0, (float*)(ws + L.slab_qkv), stream));
-      RUN(reduce_block(i, true, stream));
+      // the (full-size) qkv weight gradient of this block goes the way of every other block's: as `pending`, into the next block's
+      // merged launch on the weight-gradient stream (or the flush behind the loop) instead of 50 us of serial work here
+      static const bool defer_last_qkv = !(getenv("ROVIT_LAST_QKV_INLINE") && getenv("ROVIT_LAST_QKV_INLINE")[0] == '1');
+      if (defer_last_qkv) {
+        RUN(reduce_block(i, true, stream, 3));
+        pending = i;
+      } else {
+        RUN(rovit_wgrad(dq, 3 * D, s + L.xhat1, D, M, 3 * D, D, L.s_qkv, 0, (float*)(ws + L.slab_qkv), stream));
+        RUN(reduce_block(i, true, stream));
+      }
       continue;
     }
     const int p = i & 1;
@@ -628,9 +636,22 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
     RUN(rovit_gemm_ln_bwd(dq, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), dX, xout, sA));      // A5
     pending = i;
   }
+  auto patch_grads = [&]() -> int {          // the patch embedding's and the position embedding's gradients (block range ending at 0)
+    ROVIT_CHECK_ARG(images, ROVIT_ERR_NULL, "vit_backward: the range ending at block 0 needs the images of the forward call");
+    RUN(rovit_patch_embed_wgrad(x0v(-1), D, images, batch, T, D, L.s_pe, (float*)(ws + L.slab_pe), stream));
+    RUN(rovit_wgrad_reduce((const float*)(ws + L.slab_pe), L.s_pe, D, PD, nullptr, nullptr, nullptr, grads[P_PATCH_W], grads[P_PATCH_B],
+                           nullptr, nullptr, nullptr, stream));
+    RUN(rovit_pos_grad(dX, grads[P_POS], grads[P_CLS], batch, T, stream));
+    return ROVIT_OK;
+  };
+  bool patch_done = false;
   if (pending >= 0) {
     if (ss && !hand_over(ss, sA, sB)) EVFAIL("event hand-over");
     RUN(issue_b45(pending));
+    // the patch-embedding weight gradient (58 us, needs only the dgrad chain's final dX) runs on the caller's stream BESIDE block 0's
+    // last weight gradients on the side stream instead of behind the join
+    static const bool patch_overlap = !(getenv("ROVIT_PATCH_OVERLAP") && getenv("ROVIT_PATCH_OVERLAP")[0] == '0');
+    if (ss && last_block == 0 && patch_overlap) { RUN(patch_grads()); patch_done = true; }
     if (ss && defer_join && last_block > 0) {
       // the gradients of this range are final once B drains: tell the caller's reduction stream, do not stall A
       if (!hand_over(ss, sB, notify)) EVFAIL("event hand-over");
@@ -640,13 +661,7 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
     }
   }
 #undef EVFAIL
-  if (last_block == 0) {
-    ROVIT_CHECK_ARG(images, ROVIT_ERR_NULL, "vit_backward: the range ending at block 0 needs the images of the forward call");
-    RUN(rovit_patch_embed_wgrad(x0v(-1), D, images, batch, T, D, L.s_pe, (float*)(ws + L.slab_pe), stream));
-    RUN(rovit_wgrad_reduce((const float*)(ws + L.slab_pe), L.s_pe, D, PD, nullptr, nullptr, nullptr, grads[P_PATCH_W], grads[P_PATCH_B],
-                           nullptr, nullptr, nullptr, stream));
-    RUN(rovit_pos_grad(dX, grads[P_POS], grads[P_CLS], batch, T, stream));
-  }
+  if (last_block == 0 && !patch_done) RUN(patch_grads());
   return ROVIT_OK;
 }
 }  // namespace

@@ -560,8 +560,47 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
     if (i == depth - 1) {
       // small and serial: everything on stream A; the attention-half gradient is updated in place in xin (CLS rows)
       const int Mr = batch, rs = T;
-      char* dp = ws + L.dpre[0];
+      char* dp = ws + L.dpre[i & 1];
       char* dq = ws + L.dqkv[i & 1];
+      // Its three CLS-row weight gradients (256 rows each: 18 us apiece as separate launches, plus their reduce) run as ONE merged
+      // launch on the weight-gradient stream: for that the norm2 backward writes the bf16 gradient to the mid-block buffer instead of
+      // updating xin in place (fc2's weight gradient reads xin as it came in, proj's the updated rows).
+      static const bool cls_inline = !(getenv("ROVIT_LAST_CLS_INLINE") && getenv("ROVIT_LAST_CLS_INLINE")[0] == '0');   // (default inline until measured)
+      if (merge && !cls_inline) {
+        char* xmc = ws + L.x1[i & 1];
+        if (recompute_gelu())
+          RUN(rovit_gemm_mlp_bwd(xin, D * rs, s + L.xhat2, D * rs, q + P.wfc2T, q + P.wfc1, (const float*)(q + P.bfc1), Mr, dp, MLP * rs, stream));
+        else
+          RUN(rovit_gemm_nt(xin, D * rs, q + P.wfc2T, D, Mr, MLP, D, nullptr, EPI_MUL, dp, MLP * rs, nullptr, nullptr, 0, s + L.dact,
+                            MLP * rs, nullptr, 0, stream));
+        RUN(rovit_gemm_nt(dp, MLP * rs, q + P.wfc1T, MLP, Mr, D, MLP, nullptr, EPI_BF16, ws + L.dxhat, D * rs, nullptr, nullptr, 0, nullptr, 0,
+                          nullptr, 0, stream));
+        RUN(rovit_layernorm_bwd_rows(ws + L.dxhat, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmc, batch, T, stream));
+        ROVIT_CHECK_ARG(hipMemsetAsync(ws + L.dO, 0, (size_t)M * D * sizeof(bf16), sA) == hipSuccess, ROVIT_ERR_LAUNCH,
+                        "vit_backward: memset failed");
+        RUN(rovit_gemm_nt(xmc, D * rs, q + P.wprojT, D, Mr, D, D, nullptr, EPI_BF16, ws + L.dO, D * rs, nullptr, nullptr, 0, nullptr, 0, nullptr,
+                          0, stream));
+        if (ss && !hand_over(ss, sA, sB)) EVFAIL("event hand-over");
+        {
+          const float* const* bpp = params + P_BLOCK0 + B_COUNT * i;
+          float* const* bg = grads + P_BLOCK0 + B_COUNT * i;
+          const int sc = std::min(std::min(4, L.s_fc2c), std::min(L.s_fc1c, L.s_projc));
+          const RovitWgradDesc wd[3] = {{xin, D * rs, s + L.act, MLP * rs, D, MLP, (float*)(ws + L.slab_fc2)},
+                                        {dp, MLP * rs, s + L.xhat2, D * rs, MLP, D, (float*)(ws + L.slab_fc1)},
+                                        {xmc, D * rs, s + L.o, D * rs, D, D, (float*)(ws + L.slab_proj)}};
+          RUN(rovit_wgrad_batch(wd, 3, Mr, sc, sB));
+          const RovitReduceDesc rd[3] = {
+              {(const float*)(ws + L.slab_fc2), sc, D, MLP, nullptr, nullptr, nullptr, bg[B_FC2W], bg[B_FC2B], nullptr, nullptr, nullptr},
+              {(const float*)(ws + L.slab_fc1), sc, MLP, D, bpp[B_N2W], bpp[B_N2B], bpp[B_FC1W], bg[B_FC1W], bg[B_FC1B], bg[B_N2W], bg[B_N2B],
+               (float*)(ws + L.gscr)},
+              {(const float*)(ws + L.slab_proj), sc, D, D, nullptr, nullptr, nullptr, bg[B_PROJW], bg[B_PROJB], nullptr, nullptr, nullptr}};
+          RUN(rovit_wgrad_reduce_batch(rd, 3, sB));
+        }
+        RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, dq, batch, T, H, D / H, 0.125f, stream));
+        RUN(rovit_gemm_ln_bwd(dq, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), dX, xout, stream));
+        pending = i;
+        continue;
+      }
       if (recompute_gelu())
         RUN(rovit_gemm_mlp_bwd(xin, D * rs, s + L.xhat2, D * rs, q + P.wfc2T, q + P.wfc1, (const float*)(q + P.bfc1), Mr, dp, MLP * rs, stream));
       else

@@ -565,7 +565,7 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
       // Its three CLS-row weight gradients (256 rows each: 18 us apiece as separate launches, plus their reduce) run as ONE merged
       // launch on the weight-gradient stream: for that the norm2 backward writes the bf16 gradient to the mid-block buffer instead of
       // updating xin in place (fc2's weight gradient reads xin as it came in, proj's the updated rows).
-      static const bool cls_inline = !(getenv("ROVIT_LAST_CLS_INLINE") && getenv("ROVIT_LAST_CLS_INLINE")[0] == '0');   // (default inline until measured)
+      static const bool cls_inline = getenv("ROVIT_LAST_CLS_INLINE") && getenv("ROVIT_LAST_CLS_INLINE")[0] == '1';      // measured: 4.63 -> 4.59 ms merged
       if (merge && !cls_inline) {
         char* xmc = ws + L.x1[i & 1];
         if (recompute_gelu())

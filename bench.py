@@ -471,6 +471,123 @@ def cpu_baseline():
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def launcher_command(n, argv, port):
+    """The command `bench.py --gpus N` starts when it was NOT itself started by a launcher: one rank per GPU on this node,
+    rendezvous on 127.0.0.1 (the container hostname may not resolve), same script, same arguments."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def _fail(msg):
+    print('bench.py: ' + msg, file=sys.stderr, flush=True)
+    sys.exit(2)
+
+
+def launch_or_check_world(args, argv):
+    """Make `--gpus N` mean N ranks, loudly.  Called BEFORE anything touches the GPU (torch.cuda.device_count() does not
+    initialise it on this image), so the parent of a self-launched job never holds a device:
+      * launched by torch.distributed.run (WORLD_SIZE set): --gpus must equal WORLD_SIZE, and this rank's device must exist;
+      * not launched and --gpus N > 1: start `python -m torch.distributed.run ... bench.py <same args>` as a CHILD process
+        (never an exec), pass its output through (rank 0 prints the one JSON line) and exit with its return code;
+      * fewer than N visible devices: exit 2 with a message -- never a line that says n_gpus 1 for --gpus 8.
+    Returns only in the process that should run the benchmark itself."""
+    gloo_selftest = args.selftest_gloo
+    ws = os.environ.get('WORLD_SIZE')
+    ndev = torch.cuda.device_count() if not gloo_selftest else args.gpus
+    if ws is not None:
+        if int(ws) != args.gpus:
+            _fail(f'--gpus {args.gpus} disagrees with WORLD_SIZE={ws} set by the launcher; pass --gpus {ws} '
+                  f'(or --nproc-per-node {args.gpus})')
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        if local >= ndev:
+            _fail(f'LOCAL_RANK {local} has no device: {ndev} GPU(s) visible, {ws} ranks requested')
+        return
+    if args.gpus < 1:
+        _fail(f'--gpus must be >= 1 (got {args.gpus})')
+    if args.gpus == 1:
+        if ndev < 1:
+            _fail('no GPU visible (torch.cuda.device_count() == 0): the benchmark has no CPU fallback')
+        return
+    if ndev < args.gpus:
+        _fail(f'--gpus {args.gpus} requested but only {ndev} GPU(s) visible; refusing to report a {args.gpus}-GPU figure '
+              f'from fewer devices')
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = launcher_command(args.gpus, argv, _free_port())
+    print('bench.py: launching ' + ' '.join(cmd), file=sys.stderr, flush=True)
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        print(f'bench.py: the {args.gpus}-rank job failed with exit code {rc}', file=sys.stderr, flush=True)
+    sys.exit(rc)
+
+
+def _selftest_gloo(args):
+    """Launcher rehearsal without a GPU (tests/test_bench_launcher.py): every rank joins a gloo group, one all-reduce, rank 0
+    prints a JSON line with the world it saw.  Exercises the self-launch, the environment hand-over and the exit code."""
+    world, rank = int(os.environ['WORLD_SIZE']), int(os.environ['RANK'])
+    dist.init_process_group('gloo')
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({'selftest': 'gloo', 'n_gpus': world, 'sum_of_ranks_plus_one': float(t.item()), 'gpus_arg': args.gpus}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if args.selftest_fail_rank == rank:
+        sys.exit(7)
+
+
+def _comm_report(sync, dev, step, iters=10):
+    """What the exchange costs, measured after the timed region on rank 0's clock (all ranks run it: collectives):
+    per-bucket sizes, each bucket's all-reduce ALONE (device events, nothing else running), and the time the main stream
+    spends in GradSync.finish() inside real steps = the part of the exchange the backward did not hide."""
+    rep = {'buckets': []}
+    eng = sync.engine
+    slices = [sync.slice_for(f, l) for f, l in sync.ranges]
+    st = torch.cuda.current_stream(dev)
+    for (f, l), (off, n) in zip(sync.ranges, slices):
+        piece = eng.grad_flat[off:off + n]
+        for _ in range(3):
+            dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(iters):
+            dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+        e1.record(st)
+        e1.synchronize()
+        us = e0.elapsed_time(e1) / iters * 1e3
+        rep['buckets'].append({'blocks': [f, l], 'bytes': 4 * n, 'allreduce_alone_us': round(us, 1),
+                               'bus_GBps': round(2 * (sync.world - 1) / sync.world * 4 * n / (us * 1e-6) / 1e9, 1)})
+    evs = []
+    orig_finish = sync.finish
+
+    def timed_finish():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st)
+        orig_finish()
+        b.record(st)
+        evs.append((a, b))
+    sync.finish = timed_finish
+    try:
+        for _ in range(iters):
+            step()
+    finally:
+        sync.finish = orig_finish
+    torch.cuda.synchronize(dev)
+    rep['exposed_allreduce_us_per_step'] = round(sum(a.elapsed_time(b) for a, b in evs) / len(evs) * 1e3, 1)
+    rep['note'] = ('exposed = device time between the events around GradSync.finish() in real steps (main stream waiting for the '
+                   'reduction stream); alone = each bucket all-reduced by itself, nothing else on the device')
+    return rep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -483,6 +600,8 @@ def main():
                     help='time the step only (the command profiles/r03_bench_kernel_stats.csv is taken from: its kernel times sum to the step)')
     ap.add_argument('--roofline-only', action='store_true',
                     help='run only the roofline kernel measurements (the command profiles/r02_roofline_kernel_stats.csv and the PMC passes are taken from)')
+    ap.add_argument('--selftest-gloo', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--selftest-fail-rank', type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.roofline_only:
         dev = torch.device('cuda:0')
@@ -491,17 +610,18 @@ def main():
                           'roofline_kan': kan_roofline(dev)}), flush=True)
         return
 
+    launch_or_check_world(args, sys.argv[1:])            # returns only in a process that runs the benchmark itself
+    if args.selftest_gloo:
+        return _selftest_gloo(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus
     force_dist = os.environ.get('ROVIT_FORCE_DIST') == '1'      # exercise the RCCL code path on a single GPU
     if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if 'MASTER_PORT' not in os.environ:                  # single-process RCCL check: any free port
-            import socket
-            with socket.socket() as so:
-                so.bind(('127.0.0.1', 0))
-                os.environ['MASTER_PORT'] = str(so.getsockname()[1])
+            os.environ['MASTER_PORT'] = str(_free_port())
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         torch.cuda.set_device(local)
@@ -551,6 +671,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss)
+    rccl_world = dist.get_world_size() if dist.is_initialized() else 0
+    if world > 1 and rccl_world != args.gpus:
+        _fail(f'the RCCL group has {rccl_world} ranks, --gpus says {args.gpus}')
+    comm = _comm_report(sync, dev, step) if (world > 1 or force_dist) else None
 
     if rank == 0:
         ips = world * args.batch * args.steps / dt
@@ -563,11 +687,19 @@ def main():
                                    '224x224x3 randn images, random-init weights' % args.batch,
                        'step': 'fwd + JointLoss + bwd + grad all-reduce + clip_grad_norm(1.0) + AdamW',
                        'global_batch': world * args.batch, 'parallelism': f'dp{world}', 'grad_buckets': args.buckets,
-                       'rccl_world': dist.get_world_size() if dist.is_initialized() else 0,
+                       'rccl_world': rccl_world,
                        'backbone_mfma_frac_of_step': round(ips / world * TRAIN_FLOP_PER_IMG / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
             'final_loss': round(final_loss, 5),
         }
-        if not args.no_roofline:
+        if comm is not None:
+            res['config']['allreduce'] = comm
+            res['config']['allreduce_op'] = sync.reducer.op_name
+    if world > 1 or force_dist:
+        dist.barrier()
+        dist.destroy_process_group()       # the other ranks are done: rank 0 measures its kernels alone
+    if rank == 0:
+        # N > 1 lines carry the step and the exchange only (the kernels are the same as at N = 1; eight-rank runs stay short)
+        if not args.no_roofline and world == 1:
             res['roofline'] = wgrad_roofline(dev)
             res['roofline_attn'] = attn_roofline(dev)
             res['roofline_mlp'] = mlp_roofline(dev)
@@ -581,9 +713,6 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res), flush=True)
-    if world > 1 or force_dist:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

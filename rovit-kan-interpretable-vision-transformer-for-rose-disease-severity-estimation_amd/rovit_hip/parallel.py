@@ -46,14 +46,41 @@ class FlatBucketAllReduce:
         self.use_side_stream = use_side_stream
         self._stream: Optional[torch.cuda.Stream] = None
         self._pending = []
+        self._avg_ok: Optional[bool] = None            # decided by _check_avg on first use (RCCL only)
         self.issued: List[Tuple[int, int]] = []          # (offset, numel) log, for tests
+
+    @property
+    def op_name(self) -> str:
+        return {True: 'AVG', False: 'SUM then scale by 1/world', None: 'unchecked'}[self._avg_ok]
+
+    def _check_avg(self, device):
+        """ReduceOp.AVG had never met more than one RCCL rank before round 4's first multi-GPU run: check it ONCE on a
+        4-element tensor (rank r contributes r+1; the mean is (world+1)/2) and fall back to SUM + scale if the backend
+        rejects it or returns anything else.  Every rank takes the same decision (the check itself is a collective)."""
+        ok = True
+        try:
+            probe = torch.full((4,), float(dist.get_rank(self.group) + 1), device=device)
+            dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=self.group)
+            ok = bool((probe - (self.world + 1) / 2).abs().max().item() < 1e-6)
+        except Exception:                                 # noqa: BLE001 -- an unsupported op must not cost the run
+            ok = False
+        flag = torch.tensor([1.0 if ok else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        self._avg_ok = bool(flag.item() > 0.5)
 
     def _avg(self, t: torch.Tensor):
         if self.world == 1 and not self.force:
             return None
         backend = dist.get_backend(self.group)
         if backend == 'nccl':
-            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            if self._avg_ok is None:
+                self._check_avg(t.device)
+            if self._avg_ok:
+                return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w.wait()                                      # stream-level: the scale is ordered behind the sum on this stream
+            t.mul_(1.0 / self.world)
+            return None
         w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         w.wait()
         t.div_(self.world)
@@ -121,6 +148,8 @@ class GradSync:
             dev = params[0].device
             if dev.type == 'cuda':
                 self.engine.notify_stream = self.reducer.stream_for(dev)
+                if dist.get_backend(group) == 'nccl':
+                    self.reducer._check_avg(dev)        # decide AVG vs SUM + scale here, not inside the first backward
 
     def broadcast_parameters(self, group=None):
         """Replica identity does not depend on seeds or on which checkpoint a rank loaded: rank 0's parameters and

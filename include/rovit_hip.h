@@ -226,12 +226,6 @@ int rovit_mlp_fused_bwd(const void* dY, const void* wstream_bwd, const void* dac
                         float* dX, void* dXb, int M, rovit_stream_t stream);
 /* developer knob (timing ablations of the lockstep fused MLP kernels: bit 0 skip the row-wise epilogue, 1 skip GELU, 2 skip fc2, 3 skip fc1; results are then wrong) */
 int rovit_set_mlp_debug(int bits);
-/* developer knob (timing ablations of rovit_attention_bwd: bit 0 skip pass 1, bit 1 skip pass 2; results are then wrong) */
-int rovit_set_attn_debug(int bits);
-/* developer knob: rovit_attention_bwd as the two-pass kernel (0, default: fastest), as persistent workgroups with LDS-DMA prefetch (1:
- * 64-68 us against 57) or as the one-pass ring kernel (2: every wave owns 32 keys, dQ accumulated in an LDS tile that rotates through the
- * waves; 71 us); results agree to fp32 rounding in front of the bf16 conversion of dS */
-int rovit_set_attn_bwd_pipe(int on);
 /* token rows (batch x 197) from which rovit_vit_forward / rovit_vit_backward use rovit_mlp_fused_fwd / _bwd instead of the two-launch
  * MLP half (default 34000 = batch 173, the measured crossover; environment ROVIT_MLP_FUSED_MIN_ROWS); 0 = always fused */
 int rovit_set_mlp_fused_min_rows(int rows);

@@ -33,3 +33,15 @@ bool rovit_set_max_lds(const void* fn, size_t bytes) {
   done.emplace_back(fn, dev);
   return true;
 }
+
+#ifdef ROVIT_DEV
+int g_rovit_knob[ROVIT_KNOB_COUNT] = {0};
+bool g_rovit_knob_set[ROVIT_KNOB_COUNT] = {false};
+// developer library only (make dev): override / clear (value < 0 with clear != 0) a knob of common.h's RovitKnob list
+extern "C" int rovit_dev_set_knob(int id, int value, int clear) {
+  ROVIT_CHECK_ARG(id >= 0 && id < ROVIT_KNOB_COUNT, ROVIT_ERR_SHAPE, "dev knob %d out of range", id);
+  g_rovit_knob[id] = value;
+  g_rovit_knob_set[id] = !clear;
+  return ROVIT_OK;
+}
+#endif

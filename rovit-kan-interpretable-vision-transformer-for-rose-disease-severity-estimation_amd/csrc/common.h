@@ -40,6 +40,26 @@ bool rovit_set_max_lds(const void* fn, size_t bytes);
 
 static inline bool rovit_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+
+// ---- developer knobs (A/B timing, ablations) ------------------------------------------------------------
+// The PRODUCT library has none: ROVIT_KNOB(id, dflt) is the constant `dflt`, no debug entry point is exported, no kernel
+// that the default path cannot reach is compiled.  `make dev` builds lib/librovit_hip_dev.so with -DROVIT_DEV: there
+// rovit_dev_set_knob(id, value) (api.hip) overrides a knob for the calls that follow -- used by tools/ only
+// (ROVIT_HIP_LIB=.../librovit_hip_dev.so).
+enum RovitKnob {
+  ROVIT_KNOB_ATTN_FWD_R3 = 0,   // 1: round 3's attention forward (one workgroup per CU)
+  ROVIT_KNOB_ATTN_BWD_R3 = 1,   // 1: round 3's attention backward (one workgroup per CU, four LDS tiles)
+  ROVIT_KNOB_ATTN_DBG = 2,      // attention backward ablation bits (skip pass 1 / pass 2; results are then wrong)
+  ROVIT_KNOB_COUNT = 32
+};
+#ifdef ROVIT_DEV
+extern int g_rovit_knob[ROVIT_KNOB_COUNT];
+extern bool g_rovit_knob_set[ROVIT_KNOB_COUNT];
+#define ROVIT_KNOB(id, dflt) (g_rovit_knob_set[id] ? g_rovit_knob[id] : (dflt))
+#else
+#define ROVIT_KNOB(id, dflt) (dflt)
+#endif
+
 // ---- device helpers ------------------------------------------------------------------
 #ifdef __HIPCC__
 

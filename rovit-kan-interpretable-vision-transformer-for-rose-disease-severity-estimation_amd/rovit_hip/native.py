@@ -61,8 +61,6 @@ SIGNATURES = {
     'rovit_mlp_fused_bwd': (_i, [_vp] * 8 + [_i, _vp]),
     'rovit_set_mlp_waves': (_i, [_i]),
     'rovit_set_mlp_debug': (_i, [_i]),
-    'rovit_set_attn_debug': (_i, [_i]),
-    'rovit_set_attn_bwd_pipe': (_i, [_i]),
     'rovit_set_mlp_fused_min_rows': (_i, [_i]),
     'rovit_gemm_ln_bwd': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'rovit_set_gemm_tile': (_i, [_i]),
@@ -111,6 +109,8 @@ def load() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args
+        if hasattr(lib, 'rovit_dev_set_knob'):           # developer library (make -C csrc dev; tools/ only)
+            lib.rovit_dev_set_knob.restype, lib.rovit_dev_set_knob.argtypes = _i, [_i, _i, _i]
         if lib.rovit_version() != ABI_VERSION:
             raise RovitHipError(f'{LIB_PATH} has ABI version {lib.rovit_version()}, this binding was written for {ABI_VERSION}: '
                                 'rebuild the library (`make -C csrc`); argument lists changed between versions')

@@ -295,40 +295,66 @@ __device__ __forceinline__ void tr_wait() {
 }
 __device__ __forceinline__ bf16x8 tr_val(const TrFrag& f) { return cat4(f.lo, f.hi); }
 
-// Backward, round 4: TWO workgroups per CU (round 3: 237 VGPRs and four LDS tiles = 143 KB, one workgroup per CU, so the whole chip
-// loaded, computed and stored in lockstep: 0.34 of HBM peak with HBM idle two thirds of the launch).
-//   Pass 1: wave w owns keys [32w, 32w+32) -> dK, dV (loop over query blocks); needs the Q and dO tiles in LDS, its own K / V rows
-//           as register fragments (read straight from global memory).
-//   Pass 2: wave w owns queries [32w, 32w+32) -> dQ (loop over key blocks); needs the K and V tiles in LDS, its own Q / dO rows.
-// So only TWO tiles are live at a time: Q / dO are staged, pass 1 runs, the SAME LDS is re-staged with K / V (second read of K / V:
-// L2 / Infinity-Cache hits, +50 KB per item), pass 2 runs: 73.5 KB per workgroup.  Each pass walks the wave's two 16-row sub-tiles
-// ONE AFTER THE OTHER (accumulators 32 + 16 registers instead of 64 + 32; <= 128 VGPRs under __launch_bounds__(448, 4)), so 14
-// waves = two (image, head) items share a CU: one item's staging, re-staging and stores run under the other's passes, and four
-// waves per SIMD hide the MFMA -> exp2 -> MFMA dependency chain that the round-3 kernel software-pipelined by hand.  Price: the
-// operand fragments of a block are read from LDS once per sub-tile (2.75 MB per item = ~4.5 us of LDS time per item, spread over
-// the passes).  Sub-tiles that lie beyond T are skipped (13 of 14 at T = 197); the arithmetic per stored element is unchanged, so
-// results are bit-identical to the round-3 kernel (tools/ab_attention.py, developer library).
+// Backward, round 4: TWO workgroups per CU and TWO workgroups per (image, head).  Round 3: 237 VGPRs and four LDS tiles = 143 KB, one
+// workgroup per CU, so the whole chip loaded, computed and stored in lockstep (0.34 of HBM peak, HBM idle two thirds of the launch).
+//   Pass 1 (its own workgroup): wave w owns keys [32w, 32w+32) -> dK, dV (loop over query blocks); needs the Q and dO tiles in LDS
+//           and its own K / V rows as register fragments (read straight from global memory).
+//   Pass 2 (its own workgroup): wave w owns queries [32w, 32w+32) -> dQ (loop over key blocks); needs the K and V tiles in LDS and
+//           its own Q / dO rows.
+// The passes share nothing but the row statistics (lse, delta = rowsum(dO O): recomputed by both, 50 KB of reads that hit L2), so a
+// workgroup stages only TWO tiles (73.5 KB) and, with <= 128 VGPRs, FOUR waves per SIMD = two workgroups per CU: 2 x 768 workgroups
+// in three even rounds of 512 (768 two-pass workgroups were 1.5 rounds: the last third ran alone on its CU), a pass-1 and a pass-2
+// workgroup of different length side by side, so loads, matrix work and stores of the chip no longer move in phase.  The two
+// workgroups of an item get ids 8 apart (same XCD under round-robin dispatch, speed only) so the second finds the tiles in L2.
+//   * pass 1 walks the wave's two 16-key sub-tiles ONE AFTER THE OTHER (accumulators 32 registers instead of 64); price: the Q / dO
+//     operand fragments are read from LDS once per sub-tile;
+//   * pass 2 keeps both 16-query sub-tiles in registers (32 accumulators), K / V fragments read once per block;
+//   * transposed operands in the conflict-free column order (16 dt + 4 p: round 3's pair order, which made a lane's two tiles eight
+//     consecutive head-dim values, spread every ds_read_b64_tr_b16 over half-used bank rows: 2-way conflicts on every transposed
+//     read, 23 % of the LDS cycles); the 16-byte stores come from one v_permlane16_swap per packed register pair instead;
+//   * sub-tiles and half blocks that lie beyond T are skipped (13 of 14 sub-tiles and 13 of 14 half blocks at T = 197).
+// The arithmetic per stored element is unchanged: results are bit-identical to the round-3 kernel (tools/ab_attention.py).
 // Each pass recomputes the probabilities it needs from Q, K and lse2 in the orientation that makes them the next MFMA's operand
 // without any data movement, so there is no cross-wave reduction and no LDS traffic other than operand reads.
 __device__ __forceinline__ bf16x8 global_row_frag(const bf16* base, int ld, int row, int T, int ks, int lg) {
   const int rc = row < T ? row : T - 1;
   return keep_if(*(const bf16x8*)(base + (size_t)rc * ld + ks * 32 + lg * 8), row < T);
 }
-__global__ __launch_bounds__(NW * 64, 4) void attn_bwd_kernel(const AttnArgs a) {
+// Accumulator tiles t0 = tile 2k, t1 = tile 2k+1 of a 16-column output (lane group lg holds head-dim rows 16 dt + 4 lg + r of column
+// l15): after one v_permlane16_swap per packed register (odd 16-lane rows of the first operand <-> even rows of the second) an even
+// lane group holds tile 2k's values 8 (lg >> 1) .. + 7 and an odd one tile 2k+1's: ONE 16-byte store per lane.
+__device__ __forceinline__ void store_tile_pair(bf16* row_base, f32x4 t0, f32x4 t1, int k, int lg) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  const u32x2 x = __builtin_bit_cast(u32x2, pack4(t0)), y = __builtin_bit_cast(u32x2, pack4(t1));
+  const auto s0 = __builtin_amdgcn_permlane16_swap(x[0], y[0], false, false);
+  const auto s1 = __builtin_amdgcn_permlane16_swap(x[1], y[1], false, false);
+  u32x4 v;
+  v[0] = s0[0]; v[1] = s1[0]; v[2] = s0[1]; v[3] = s1[1];
+  *(u32x4*)(row_base + 16 * (2 * k + (lg & 1)) + 8 * (lg >> 1)) = v;
+}
+__global__ __launch_bounds__(NW * 64, 4) void attn_bwd_kernel(const AttnArgs a, int n_items) {
   extern __shared__ __attribute__((aligned(16))) bf16 lds[];
-  bf16* T0 = lds;                                // Q, then K
-  bf16* T1 = T0 + TP * AST;                      // dO, then V
+  bf16* T0 = lds;                                // pass 1: Q,  pass 2: K
+  bf16* T1 = T0 + TP * AST;                      // pass 1: dO, pass 2: V
   float* s_lse = (float*)(T1 + TP * AST);        // [TP]
   float* s_del = s_lse + TP;                     // [TP]  -rowsum(dO * O)
-  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const int pass = (blockIdx.x >> 3) & 1;
+  const int bh = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+  if (bh >= n_items) return;                     // whole workgroup
+  const int b = bh / a.H, h = bh - b * a.H;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
   const int ld = 3 * a.H * HD, ldo = a.H * HD;
   const bf16* base = a.qkv + (size_t)b * a.T * ld + h * HD;
   const bf16* gbase = a.dout + (size_t)b * a.T * ldo + h * HD;
   const bf16* obase = a.out + (size_t)b * a.T * ldo + h * HD;
-  stage_tile(T0, base, ld, a.T, tid);
-  stage_tile(T1, gbase, ldo, a.T, tid);
+  if (pass == 0) {
+    stage_tile(T0, base, ld, a.T, tid);
+    stage_tile(T1, gbase, ldo, a.T, tid);
+  } else {
+    stage_tile(T0, base + a.H * HD, ld, a.T, tid);
+    stage_tile(T1, base + 2 * a.H * HD, ld, a.T, tid);
+  }
   {
     const int row = tid >> 1, half = tid & 1;     // 448 threads = 224 rows x 2 halves
     float d = 0.f;
@@ -355,107 +381,128 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_kernel(const AttnArgs a) 
   const int nblk = (a.T + 31) >> 5;              // 32-row blocks that hold real rows (7 at T = 197)
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  // ---------------- pass 1: dK, dV for keys [32w, 32w+32), 16 keys at a time ----------------
-  // Per score the vector work is one FMA, one exp2 and one multiply: padded Q / dO rows are ZERO in LDS (their P dO and dS Q terms
-  // are exact zeros), `- delta` is the initial accumulator of the dP chain, the factor `scale` rides on the probability.
+  if (pass == 0) {
+    // ---------------- pass 1: dK, dV for keys [32w, 32w+32), 16 keys at a time ----------------
+    // Per score the vector work is one FMA, one exp2 and one multiply: padded Q / dO rows are ZERO in LDS (their P dO and dS Q
+    // terms are exact zeros), `- delta` is the initial accumulator of the dP chain, the factor `scale` rides on the probability.
 #pragma unroll 1
-  for (int kt = 0; kt < 2; ++kt) {
-    const int key0 = 32 * w + 16 * kt;
-    if (key0 >= a.T || ATTN_DBG(a, 1)) break;         // wave-uniform
-    const int key = key0 + l15;
-    bf16x8 kf[2], vf[2];
+    for (int kt = 0; kt < 2; ++kt) {
+      const int key0 = 32 * w + 16 * kt;
+      if (key0 >= a.T || ATTN_DBG(a, 1)) break;         // wave-uniform
+      const int key = key0 + l15;
+      bf16x8 kf[2], vf[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      kf[ks] = global_row_frag(base + a.H * HD, ld, key, a.T, ks, lg);
-      vf[ks] = global_row_frag(base + 2 * a.H * HD, ld, key, a.T, ks, lg);
-    }
-    f32x4 dv[4] = {zero4, zero4, zero4, zero4}, dk[4] = {zero4, zero4, zero4, zero4};
+      for (int ks = 0; ks < 2; ++ks) {
+        kf[ks] = global_row_frag(base + a.H * HD, ld, key, a.T, ks, lg);
+        vf[ks] = global_row_frag(base + 2 * a.H * HD, ld, key, a.T, ks, lg);
+      }
+      f32x4 dv[4] = {zero4, zero4, zero4, zero4}, dk[4] = {zero4, zero4, zero4, zero4};
 #pragma unroll 1
-    for (int qb = 0; qb < nblk; ++qb) {
-      f32x4 p[2], ds[2];                 // rows q = 32qb + 16qt + 4lg + r, col key
+      for (int qb = 0; qb < nblk; ++qb) {
+        f32x4 p[2] = {zero4, zero4}, ds[2] = {zero4, zero4};       // rows q = 32qb + 16qt + 4lg + r, col key
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        const int qr = 32 * qb + 16 * qt + l15;
-        const float4 del4 = *(const float4*)(s_del + 32 * qb + 16 * qt + 4 * lg);
-        const f32x4 nd = {del4.x, del4.y, del4.z, del4.w};
-        const f32x4 s = mfma16(row_frag(T0, qr, 1, lg), kf[1], mfma16(row_frag(T0, qr, 0, lg), kf[0], zero4));
-        const f32x4 dp = mfma16(row_frag(T1, qr, 1, lg), vf[1], mfma16(row_frag(T1, qr, 0, lg), vf[0], nd));
-        const float4 lse4 = *(const float4*)(s_lse + 32 * qb + 16 * qt + 4 * lg);
-        const float lse_r[4] = {lse4.x, lse4.y, lse4.z, lse4.w};
+        for (int qt = 0; qt < 2; ++qt) {
+          if (qt == 1 && 32 * qb + 16 >= a.T) break;               // wave-uniform: the half block holds padded queries only (P dO = dS Q = 0)
+          const int qr = 32 * qb + 16 * qt + l15;
+          const float4 del4 = *(const float4*)(s_del + 32 * qb + 16 * qt + 4 * lg);
+          const f32x4 nd = {del4.x, del4.y, del4.z, del4.w};
+          const f32x4 s = mfma16(row_frag(T0, qr, 1, lg), kf[1], mfma16(row_frag(T0, qr, 0, lg), kf[0], zero4));
+          const f32x4 dp = mfma16(row_frag(T1, qr, 1, lg), vf[1], mfma16(row_frag(T1, qr, 0, lg), vf[0], nd));
+          const float4 lse4 = *(const float4*)(s_lse + 32 * qb + 16 * qt + 4 * lg);
+          const float lse_r[4] = {lse4.x, lse4.y, lse4.z, lse4.w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse_r[r]));     // P scale
-          p[qt][r] = pr;
-          ds[qt][r] = pr * dp[r];
+          for (int r = 0; r < 4; ++r) {
+            const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse_r[r]));     // P scale
+            p[qt][r] = pr;
+            ds[qt][r] = pr * dp[r];
+          }
+        }
+        const bf16x8 pf = pack8(p[0], p[1]), dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dv[dt] = mfma16(col_frag(T1, 32 * qb, dt, l15, lg), pf, dv[dt]);            // dV^T[d][key] (x scale); rows = d, slots = queries
+          dk[dt] = mfma16(col_frag(T0, 32 * qb, dt, l15, lg), dsf, dk[dt]);           // dK^T[d][key]
         }
       }
-      const bf16x8 pf = pack8(p[0], p[1]), dsf = pack8(ds[0], ds[1]);
+      // (v_permlane16_swap pairs lanes l and l ^ 16, which hold the SAME key: both inside or both outside the `key < T` branch)
+      bf16* dst = a.dqkv + ((size_t)b * a.T + (key < a.T ? key : a.T - 1)) * ld + h * HD;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        dv[dt] = mfma16(tr_frag(T1, 32 * qb, dt, l15, lg), pf, dv[dt]);            // dV^T[d][key] (x scale); rows = d, slots = queries
-        dk[dt] = mfma16(tr_frag(T0, 32 * qb, dt, l15, lg), dsf, dk[dt]);           // dK^T[d][key]
-      }
-    }
-    if (key < a.T) {
-      bf16* dst = a.dqkv + ((size_t)b * a.T + key) * ld + h * HD + 8 * lg;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {             // tile pair (2k, 2k+1) = head-dim values 32k + 8lg .. +7 (see tr_frag)
+      for (int k = 0; k < 2; ++k) {
         f32x4 v0 = dv[2 * k], v1 = dv[2 * k + 1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v0[r] *= 8.f; v1[r] *= 8.f; }      // dV summed P scale: x 8, exact
-        *(bf16x8*)(dst + a.H * HD + 32 * k) = pack8(dk[2 * k], dk[2 * k + 1]);
-        *(bf16x8*)(dst + 2 * a.H * HD + 32 * k) = pack8(v0, v1);
+        if (key < a.T) {
+          store_tile_pair(dst + a.H * HD, dk[2 * k], dk[2 * k + 1], k, lg);
+          store_tile_pair(dst + 2 * a.H * HD, v0, v1, k, lg);
+        }
       }
     }
-  }
-
-  // ---------------- the same LDS now holds K and V ----------------
-  __syncthreads();                                // every wave is done with the Q / dO tiles
-  stage_tile(T0, base + a.H * HD, ld, a.T, tid);
-  stage_tile(T1, base + 2 * a.H * HD, ld, a.T, tid);
-  __syncthreads();
-
-  // ---------------- pass 2: dQ for queries [32w, 32w+32), 16 queries at a time ----------------
-#pragma unroll 1
-  for (int qt = 0; qt < 2; ++qt) {
-    const int q0 = 32 * w + 16 * qt;
-    if (q0 >= a.T || ATTN_DBG(a, 2)) break;
-    const int qr = q0 + l15;
-    bf16x8 qf[2], gf[2];
+  } else {
+    // ---------------- pass 2: dQ for queries [32w, 32w+32), both 16-query sub-tiles in registers ----------------
+    if (32 * w >= a.T || ATTN_DBG(a, 2)) return;       // wave-uniform; no barrier follows
+    const bool two = 32 * w + 16 < a.T;                // the second sub-tile holds real queries
+    bf16x8 qf[2][2], gf[2][2];
+    float lq[2];
+    f32x4 ndq[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      qf[ks] = global_row_frag(base, ld, qr, a.T, ks, lg);
-      gf[ks] = global_row_frag(gbase, ldo, qr, a.T, ks, lg);
+    for (int qt = 0; qt < 2; ++qt) {
+      const int qr = 32 * w + 16 * qt + l15;
+      lq[qt] = s_lse[qr];
+      const float nd = s_del[qr];
+      ndq[qt] = (f32x4){nd, nd, nd, nd};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        qf[qt][ks] = global_row_frag(base, ld, qr, a.T, ks, lg);
+        gf[qt][ks] = global_row_frag(gbase, ldo, qr, a.T, ks, lg);
+      }
     }
-    const float lq = s_lse[qr], nd = s_del[qr];
-    const f32x4 ndq = {nd, nd, nd, nd};
-    f32x4 dq[4] = {zero4, zero4, zero4, zero4};
+    f32x4 dq[4][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) dq[dt][qt] = zero4;
 #pragma unroll 1
     for (int kb = 0; kb < nblk; ++kb) {
-      f32x4 ds[2];                       // rows key = 32kb + 16kt + 4lg + r, col q
+      f32x4 ds[2][2] = {{zero4, zero4}, {zero4, zero4}};       // [kt][qt]: rows key = 32kb + 16kt + 4lg + r, col q
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
+        if (kt == 1 && 32 * kb + 16 >= a.T) break;             // wave-uniform: padded keys only
         const int kr = 32 * kb + 16 * kt + l15;
-        const f32x4 s = mfma16(row_frag(T0, kr, 1, lg), qf[1], mfma16(row_frag(T0, kr, 0, lg), qf[0], zero4));
-        const f32x4 dp = mfma16(row_frag(T1, kr, 1, lg), gf[1], mfma16(row_frag(T1, kr, 0, lg), gf[0], ndq));
+        const bf16x8 k0 = row_frag(T0, kr, 0, lg), k1 = row_frag(T0, kr, 1, lg);
+        const bf16x8 v0 = row_frag(T1, kr, 0, lg), v1 = row_frag(T1, kr, 1, lg);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ds[kt][r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lq)) * dp[r];
+        for (int qt = 0; qt < 2; ++qt) {
+          if (qt == 1 && !two) break;
+          const f32x4 s = mfma16(k1, qf[qt][1], mfma16(k0, qf[qt][0], zero4));
+          const f32x4 dp = mfma16(v1, gf[qt][1], mfma16(v0, gf[qt][0], ndq[qt]));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ds[kt][qt][r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lq[qt])) * dp[r];
+        }
       }
       if (32 * kb + 32 > a.T) {          // wave-uniform, last block only: a padded key has score 0 and dP - delta = -delta, and only
 #pragma unroll                           // its zero K row cancelled exp2(-lse) (-delta) -- which is Inf 0 = NaN once lse < -125
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (32 * kb + 16 * kt + 4 * lg + r >= a.T) ds[kt][r] = 0.f;
+          for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (32 * kb + 16 * kt + 4 * lg + r >= a.T) ds[kt][qt][r] = 0.f;
       }
-      const bf16x8 dsf = pack8(ds[0], ds[1]);
+      const bf16x8 dsf0 = pack8(ds[0][0], ds[1][0]), dsf1 = pack8(ds[0][1], ds[1][1]);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(tr_frag(T0, 32 * kb, dt, l15, lg), dsf, dq[dt]);   // dQ^T[d][q]; rows = d, slots = keys
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 kT = col_frag(T0, 32 * kb, dt, l15, lg);                        // rows = d, slots = keys
+        dq[dt][0] = mfma16(kT, dsf0, dq[dt][0]);                                     // dQ^T[d][q]
+        if (two) dq[dt][1] = mfma16(kT, dsf1, dq[dt][1]);
+      }
     }
-    if (qr < a.T) {
-      bf16* dst = a.dqkv + ((size_t)b * a.T + qr) * ld + h * HD + 8 * lg;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) *(bf16x8*)(dst + 32 * k) = pack8(dq[2 * k], dq[2 * k + 1]);
+    for (int qt = 0; qt < 2; ++qt) {
+      const int qr = 32 * w + 16 * qt + l15;
+      bf16* dst = a.dqkv + ((size_t)b * a.T + (qr < a.T ? qr : a.T - 1)) * ld + h * HD;
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (qr < a.T) store_tile_pair(dst, dq[2 * k][qt], dq[2 * k + 1][qt], k, lg);
     }
   }
 }
@@ -794,7 +841,8 @@ extern "C" int rovit_attention_bwd(const void* qkv, const void* out, const float
 #endif
   const size_t lds = (size_t)2 * TP * AST * sizeof(bf16) + 2 * TP * sizeof(float);
   ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)attn_bwd_kernel, lds), ROVIT_ERR_LAUNCH, "attention_bwd: cannot raise the LDS limit");
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(batch * heads), dim3(NW * 64), lds, (hipStream_t)stream, a);
+  const int items = batch * heads;
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(((items + 7) / 8) * 16), dim3(NW * 64), lds, (hipStream_t)stream, a, items);
   ROVIT_CHECK_LAUNCH("attn_bwd_kernel");
   return ROVIT_OK;
 }

@@ -13,6 +13,7 @@
 //     holds it; the matching V^T / K^T / Q^T / dO^T operands are gathered with ds_read_b64_tr_b16.
 // No score/probability tile ever touches LDS or HBM.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -342,7 +343,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_kernel(const AttnArgs a, 
   const int bh = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
   if (bh >= n_items) return;                     // whole workgroup
   const int b = bh / a.H, h = bh - b * a.H;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: the sub-tile skips below become scalar branches
   const int l15 = lane & 15, lg = lane >> 4;
   const int ld = 3 * a.H * HD, ldo = a.H * HD;
   const bf16* base = a.qkv + (size_t)b * a.T * ld + h * HD;
@@ -378,8 +380,14 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_kernel(const AttnArgs a, 
   __syncthreads();
   const float c2 = a.scale * LOG2E;
   static_assert(HD == 64, "scale = 2^-3 is folded into the exponent offset");
-  const int nblk = (a.T + 31) >> 5;              // 32-row blocks that hold real rows (7 at T = 197)
+  // The block loops are ONE basic block each (a wave-uniform `break` inside the body split it, and the scheduler no longer interleaved
+  // the LDS reads, the MFMAs and the exp2 chain of an iteration: pass 1 went from 22 to 40 us): full 32-row blocks run the plain body,
+  // the last, partial block runs a peeled copy that masks padded keys (pass 2) and drops a half that holds padded rows only.
+  const int nfull = a.T >> 5, tail = a.T & 31;   // 6 full blocks + 5 rows at T = 197
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  typedef std::integral_constant<int, 0> Full;
+  typedef std::integral_constant<int, 1> TailBoth;
+  typedef std::integral_constant<int, 2> TailHalf;
 
   if (pass == 0) {
     // ---------------- pass 1: dK, dV for keys [32w, 32w+32), 16 keys at a time ----------------
@@ -397,12 +405,11 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_kernel(const AttnArgs a, 
         vf[ks] = global_row_frag(base + 2 * a.H * HD, ld, key, a.T, ks, lg);
       }
       f32x4 dv[4] = {zero4, zero4, zero4, zero4}, dk[4] = {zero4, zero4, zero4, zero4};
-#pragma unroll 1
-      for (int qb = 0; qb < nblk; ++qb) {
+      auto block = [&](int qb, auto mode) {
+        constexpr int NQT = decltype(mode)::value == 2 ? 1 : 2;     // TailHalf: the second 16 queries are padding (P dO = dS Q = 0)
         f32x4 p[2] = {zero4, zero4}, ds[2] = {zero4, zero4};       // rows q = 32qb + 16qt + 4lg + r, col key
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-          if (qt == 1 && 32 * qb + 16 >= a.T) break;               // wave-uniform: the half block holds padded queries only (P dO = dS Q = 0)
+        for (int qt = 0; qt < NQT; ++qt) {
           const int qr = 32 * qb + 16 * qt + l15;
           const float4 del4 = *(const float4*)(s_del + 32 * qb + 16 * qt + 4 * lg);
           const f32x4 nd = {del4.x, del4.y, del4.z, del4.w};
@@ -423,7 +430,11 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_kernel(const AttnArgs a, 
           dv[dt] = mfma16(col_frag(T1, 32 * qb, dt, l15, lg), pf, dv[dt]);            // dV^T[d][key] (x scale); rows = d, slots = queries
           dk[dt] = mfma16(col_frag(T0, 32 * qb, dt, l15, lg), dsf, dk[dt]);           // dK^T[d][key]
         }
-      }
+      };
+#pragma unroll 1
+      for (int qb = 0; qb < nfull; ++qb) block(qb, Full());
+      if (tail > 16) block(nfull, Full());
+      else if (tail > 0) block(nfull, TailHalf());
       // (v_permlane16_swap pairs lanes l and l ^ 16, which hold the SAME key: both inside or both outside the `key < T` branch)
       bf16* dst = a.dqkv + ((size_t)b * a.T + (key < a.T ? key : a.T - 1)) * ld + h * HD;
 #pragma unroll
@@ -440,7 +451,6 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_kernel(const AttnArgs a, 
   } else {
     // ---------------- pass 2: dQ for queries [32w, 32w+32), both 16-query sub-tiles in registers ----------------
     if (32 * w >= a.T || ATTN_DBG(a, 2)) return;       // wave-uniform; no barrier follows
-    const bool two = 32 * w + 16 < a.T;                // the second sub-tile holds real queries
     bf16x8 qf[2][2], gf[2][2];
     float lq[2];
     f32x4 ndq[2];
@@ -461,41 +471,46 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_kernel(const AttnArgs a, 
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) dq[dt][qt] = zero4;
-#pragma unroll 1
-    for (int kb = 0; kb < nblk; ++kb) {
+    auto block = [&](int kb, auto mode, auto nq) {
+      constexpr int MODE = decltype(mode)::value, NKT = MODE == 2 ? 1 : 2, NQT = decltype(nq)::value;
       f32x4 ds[2][2] = {{zero4, zero4}, {zero4, zero4}};       // [kt][qt]: rows key = 32kb + 16kt + 4lg + r, col q
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        if (kt == 1 && 32 * kb + 16 >= a.T) break;             // wave-uniform: padded keys only
+      for (int kt = 0; kt < NKT; ++kt) {
         const int kr = 32 * kb + 16 * kt + l15;
         const bf16x8 k0 = row_frag(T0, kr, 0, lg), k1 = row_frag(T0, kr, 1, lg);
         const bf16x8 v0 = row_frag(T1, kr, 0, lg), v1 = row_frag(T1, kr, 1, lg);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-          if (qt == 1 && !two) break;
+        for (int qt = 0; qt < NQT; ++qt) {
           const f32x4 s = mfma16(k1, qf[qt][1], mfma16(k0, qf[qt][0], zero4));
           const f32x4 dp = mfma16(v1, gf[qt][1], mfma16(v0, gf[qt][0], ndq[qt]));
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ds[kt][qt][r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lq[qt])) * dp[r];
+          for (int r = 0; r < 4; ++r) {
+            float v = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lq[qt])) * dp[r];
+            // last block only: a padded key has score 0 and dP - delta = -delta, and only its zero K row cancelled
+            // exp2(-lse) (-delta) -- which is Inf 0 = NaN once lse < -125
+            if (MODE != 0 && 32 * kb + 16 * kt + 4 * lg + r >= a.T) v = 0.f;
+            ds[kt][qt][r] = v;
+          }
         }
       }
-      if (32 * kb + 32 > a.T) {          // wave-uniform, last block only: a padded key has score 0 and dP - delta = -delta, and only
-#pragma unroll                           // its zero K row cancelled exp2(-lse) (-delta) -- which is Inf 0 = NaN once lse < -125
-        for (int kt = 0; kt < 2; ++kt)
+      bf16x8 dsf[2];
 #pragma unroll
-          for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (32 * kb + 16 * kt + 4 * lg + r >= a.T) ds[kt][qt][r] = 0.f;
-      }
-      const bf16x8 dsf0 = pack8(ds[0][0], ds[1][0]), dsf1 = pack8(ds[0][1], ds[1][1]);
+      for (int qt = 0; qt < NQT; ++qt) dsf[qt] = pack8(ds[0][qt], ds[1][qt]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const bf16x8 kT = col_frag(T0, 32 * kb, dt, l15, lg);                        // rows = d, slots = keys
-        dq[dt][0] = mfma16(kT, dsf0, dq[dt][0]);                                     // dQ^T[d][q]
-        if (two) dq[dt][1] = mfma16(kT, dsf1, dq[dt][1]);
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) dq[dt][qt] = mfma16(kT, dsf[qt], dq[dt][qt]);   // dQ^T[d][q]
       }
-    }
+    };
+    auto sweep = [&](auto nq) {
+#pragma unroll 1
+      for (int kb = 0; kb < nfull; ++kb) block(kb, Full(), nq);
+      if (tail > 16) block(nfull, TailBoth(), nq);
+      else if (tail > 0) block(nfull, TailHalf(), nq);
+    };
+    if (32 * w + 16 < a.T) sweep(std::integral_constant<int, 2>());
+    else sweep(std::integral_constant<int, 1>());         // the wave's second sub-tile holds padded queries only
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       const int qr = 32 * w + 16 * qt + l15;

@@ -305,8 +305,7 @@ __device__ __forceinline__ bf16x8 tr_val(const TrFrag& f) { return cat4(f.lo, f.
 // The passes share nothing but the row statistics (lse, delta = rowsum(dO O): recomputed by both, 50 KB of reads that hit L2), so a
 // workgroup stages only TWO tiles (73.5 KB) and, with <= 128 VGPRs, FOUR waves per SIMD = two workgroups per CU: 2 x 768 workgroups
 // in three even rounds of 512 (768 two-pass workgroups were 1.5 rounds: the last third ran alone on its CU), a pass-1 and a pass-2
-// workgroup of different length side by side, so loads, matrix work and stores of the chip no longer move in phase.  The two
-// workgroups of an item get ids 8 apart (same XCD under round-robin dispatch, speed only) so the second finds the tiles in L2.
+// workgroup of different length side by side, so loads, matrix work and stores of the chip no longer move in phase.
 //   * pass 1 walks the wave's two 16-key sub-tiles ONE AFTER THE OTHER (accumulators 32 registers instead of 64); price: the Q / dO
 //     operand fragments are read from LDS once per sub-tile;
 //   * pass 2 keeps both 16-query sub-tiles in registers (32 accumulators), K / V fragments read once per block;
@@ -333,14 +332,21 @@ __device__ __forceinline__ void store_tile_pair(bf16* row_base, f32x4 t0, f32x4 
   v[0] = s0[0]; v[1] = s1[0]; v[2] = s0[1]; v[3] = s1[1];
   *(u32x4*)(row_base + 16 * (2 * k + (lg & 1)) + 8 * (lg >> 1)) = v;
 }
+template <bool SPLIT>
 __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_kernel(const AttnArgs a, int n_items) {
   extern __shared__ __attribute__((aligned(16))) bf16 lds[];
   bf16* T0 = lds;                                // pass 1: Q,  pass 2: K
   bf16* T1 = T0 + TP * AST;                      // pass 1: dO, pass 2: V
   float* s_lse = (float*)(T1 + TP * AST);        // [TP]
   float* s_del = s_lse + TP;                     // [TP]  -rowsum(dO * O)
-  const int pass = (blockIdx.x >> 3) & 1;
-  const int bh = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+  // Workgroup id -> (item, pass).  Ids b, b + 8, ... share an XCD (round-robin dispatch) and are dealt to its 32 CUs in turn, so
+  // `pass = (id >> 3) & 1` put every pass-1 workgroup on an even CU and every (lighter) pass-2 workgroup on an odd one: 66 us.
+  // Here the j-th workgroup of an XCD (j = id >> 3) belongs to group j >> 6 of 32 items; the first 32 of a group run pass 1, the
+  // next 32 pass 2 of the same items: one of each per CU in the first round, and an item's two workgroups share the XCD's L2.
+  // Speed only: any placement gives the same results.
+  const int j = blockIdx.x >> 3;
+  const int pass = SPLIT ? (j >> 5) & 1 : 0;     // !SPLIT: one workgroup per item runs pass 1, re-stages the same LDS with K / V, runs pass 2
+  const int bh = SPLIT ? ((j >> 6) * 32 + (j & 31)) * 8 + (blockIdx.x & 7) : (int)blockIdx.x;
   if (bh >= n_items) return;                     // whole workgroup
   const int b = bh / a.H, h = bh - b * a.H;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -448,7 +454,14 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_kernel(const AttnArgs a, 
         }
       }
     }
-  } else {
+  }
+  if (!SPLIT) {
+    __syncthreads();                               // every wave is done with the Q / dO tiles
+    stage_tile(T0, base + a.H * HD, ld, a.T, tid);
+    stage_tile(T1, base + 2 * a.H * HD, ld, a.T, tid);
+    __syncthreads();
+  }
+  if (!SPLIT || pass == 1) {
     // ---------------- pass 2: dQ for queries [32w, 32w+32), both 16-query sub-tiles in registers ----------------
     if (32 * w >= a.T || ATTN_DBG(a, 2)) return;       // wave-uniform; no barrier follows
     bf16x8 qf[2][2], gf[2][2];
@@ -855,9 +868,18 @@ extern "C" int rovit_attention_bwd(const void* qkv, const void* out, const float
   }
 #endif
   const size_t lds = (size_t)2 * TP * AST * sizeof(bf16) + 2 * TP * sizeof(float);
-  ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)attn_bwd_kernel, lds), ROVIT_ERR_LAUNCH, "attention_bwd: cannot raise the LDS limit");
+  ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)attn_bwd_kernel<false>, lds), ROVIT_ERR_LAUNCH, "attention_bwd: cannot raise the LDS limit");
   const int items = batch * heads;
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(((items + 7) / 8) * 16), dim3(NW * 64), lds, (hipStream_t)stream, a, items);
+#ifdef ROVIT_DEV
+  if (ROVIT_KNOB(ROVIT_KNOB_ATTN_BWD_SPLIT, 0)) {
+    ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)attn_bwd_kernel<true>, lds), ROVIT_ERR_LAUNCH, "attention_bwd: cannot raise the LDS limit");
+    const int groups = ((items + 7) / 8 + 31) / 32;          // groups of 32 items per XCD label; 2 x 32 x 8 workgroups each
+    hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(groups * 512), dim3(NW * 64), lds, (hipStream_t)stream, a, items);
+    ROVIT_CHECK_LAUNCH("attn_bwd_kernel<split>");
+    return ROVIT_OK;
+  }
+#endif
+  hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(items), dim3(NW * 64), lds, (hipStream_t)stream, a, items);
   ROVIT_CHECK_LAUNCH("attn_bwd_kernel");
   return ROVIT_OK;
 }

@@ -50,6 +50,7 @@ enum RovitKnob {
   ROVIT_KNOB_ATTN_FWD_R3 = 0,   // 1: round 3's attention forward (one workgroup per CU)
   ROVIT_KNOB_ATTN_BWD_R3 = 1,   // 1: round 3's attention backward (one workgroup per CU, four LDS tiles)
   ROVIT_KNOB_ATTN_DBG = 2,      // attention backward ablation bits (skip pass 1 / pass 2; results are then wrong)
+  ROVIT_KNOB_ATTN_BWD_SPLIT = 3, // 1: attention backward with the two passes as separate workgroups (measured slower: 62 us against 50)
   ROVIT_KNOB_COUNT = 32
 };
 #ifdef ROVIT_DEV

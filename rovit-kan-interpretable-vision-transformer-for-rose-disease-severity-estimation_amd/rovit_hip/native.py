@@ -111,6 +111,11 @@ def load() -> C.CDLL:
             fn.restype, fn.argtypes = res, args
         if hasattr(lib, 'rovit_dev_set_knob'):           # developer library (make -C csrc dev; tools/ only)
             lib.rovit_dev_set_knob.restype, lib.rovit_dev_set_knob.argtypes = _i, [_i, _i, _i]
+            # A/B of whole steps with the developer library: ROVIT_DEV_KNOBS="id=value,id=value" (common.h RovitKnob ids).
+            # The product library exports no such entry point, so the variable does nothing there.
+            for kv in filter(None, os.environ.get('ROVIT_DEV_KNOBS', '').split(',')):
+                k, v = kv.split('=')
+                lib.rovit_dev_set_knob(int(k), int(v), 0)
         if lib.rovit_version() != ABI_VERSION:
             raise RovitHipError(f'{LIB_PATH} has ABI version {lib.rovit_version()}, this binding was written for {ABI_VERSION}: '
                                 'rebuild the library (`make -C csrc`); argument lists changed between versions')

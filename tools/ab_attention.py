@@ -12,7 +12,7 @@ sys.path[:0] = [ROOT, PKG]
 import torch  # noqa: E402
 from rovit_hip import native  # noqa: E402
 
-KNOB_FWD_R3, KNOB_BWD_R3, KNOB_DBG = 0, 1, 2
+KNOB_FWD_R3, KNOB_BWD_R3, KNOB_DBG, KNOB_SPLIT = 0, 1, 2, 3
 
 
 def main():
@@ -81,6 +81,13 @@ def main():
             res.setdefault(f'fwd_b2b_us_{tag}', []).append(round(timed(fwd, per_launch=False), 2))
             res.setdefault(f'bwd_us_{tag}', []).append(round(timed(bwd), 2))
             res.setdefault(f'bwd_b2b_us_{tag}', []).append(round(timed(bwd, per_launch=False), 2))
+    lib.rovit_dev_set_knob(KNOB_BWD_R3, 0, 0)
+    lib.rovit_dev_set_knob(KNOB_SPLIT, 1, 0)             # the passes as separate workgroups (two per item)
+    dqkv.fill_(float('nan')); bwd(); torch.cuda.synchronize()
+    res['bwd_split_bit_identical'] = bool(torch.equal(dqkv.view(torch.int16), outs[0][2].view(torch.int16)))
+    for rep in range(3):
+        res.setdefault('bwd_us_r4_split', []).append(round(timed(bwd), 2))
+    lib.rovit_dev_set_knob(KNOB_SPLIT, 0, 1)
     for r3 in (1, 0):
         tag = 'r3' if r3 else 'r4'
         lib.rovit_dev_set_knob(KNOB_BWD_R3, r3, 0)

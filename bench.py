@@ -262,6 +262,24 @@ def wgrad_roofline(dev, iters=30):
             'mfma_tflops': round(flops / (ms * 1e-3) / 1e12, 1)}
 
 
+def fp32_mode(dev, batch=256, iters=5):
+    """The reference-precision forward (DeiTTiny.precision = 'fp32': every product and sum in fp32, GEMMs and attention on
+    v_mfma_f32_32x32x2_f32) at the benchmark's batch: the only mode that meets north_star's 1e-3 / identical-argmax clause
+    end to end (tests/test_gpu_round2.py::test_fp32_reference_precision_mode...).  Whole model forward, device events."""
+    from models.rovit_kan import RoViTKAN
+    torch.manual_seed(0)
+    m = RoViTKAN(pretrained=False).to(dev).eval()
+    m.curriculum_stage = 4
+    m.backbone.model.precision = 'fp32'
+    x = torch.randn(batch, 3, 224, 224, device=dev)
+    with torch.no_grad():
+        ms = _event_avg_ms(dev, lambda: m(x), iters, per_launch=False)
+    tf = FWD_FLOP_PER_IMG * batch / (ms * 1e-3) / 1e12
+    return {'ms_per_forward': round(ms, 3), 'images_per_sec': round(batch / (ms * 1e-3), 1), 'batch': batch,
+            'fp32_tflops': round(tf, 1), 'frac_of_fp32_matrix_peak': round(tf / FP32_PEAK_TFLOPS, 4),
+            'kernels': 'gemm_f32_mfma_kernel (128x192 tiles), attn_f32_mfma_kernel: v_mfma_f32_32x32x2_f32, exact fp32 FMA chains'}
+
+
 def kan_roofline(dev, iters=30):
     """KAN spline head (north_star: HBM roofline, no MFMA), kernels only (direct C-ABI calls):
     C5 = BASELINE.json configs[4] (num_knots 32, batch 512: three per-layer launches, the faster path at that size) and
@@ -704,6 +722,7 @@ def main():
             res['roofline_attn'] = attn_roofline(dev)
             res['roofline_mlp'] = mlp_roofline(dev)
             res['roofline_kan'] = kan_roofline(dev)
+            res['fp32_mode'] = fp32_mode(dev)
             attn_us = sum(v['avg_us'] for v in res['roofline_attn'].values())
             attn_floor_us = sum(v['algorithmic_bytes'] for v in res['roofline_attn'].values()) / (HBM_PEAK_GBS * 1e9) * 1e6
             # images/sec as a fraction of the attention-GEMM roofline (north_star): the six attention kernels of one block

@@ -5,9 +5,13 @@
 // reference's own CUDA autocast path), which moves the features by ~5e-3 RMS -- enough to carry a feature across the
 // discontinuity of the reference's truncated spline.  This path runs the SAME arithmetic (timm VisionTransformer.forward,
 // SURVEY.md section 2, reached from /root/reference/models/backbone.py:12-25) entirely in fp32 on the GPU, so the end-to-end
-// parity statement can be made at fp32 tolerance.  It is a parity / evaluation mode, not the fast path: plain tiled VALU
-// kernels (exact fp32 FMAs, no MFMA, no bf16 anywhere), ~30x slower than the bf16 path.
+// parity statement can be made at fp32 tolerance.  Round 4: the GEMMs and the two attention products run on the fp32 matrix
+// cores (v_mfma_f32_32x32x2_f32: fp32 operands, every product and sum an exact fp32 FMA chain in a fixed k order, no bf16
+// anywhere -- MI355X_MICROARCH.md "FP32-input MFMA"), 157 TFLOP/s peak = 1/16 of the bf16 rate; the round-2 VALU tiles ran at
+// 41 TFLOP/s (15.5 ms per 256 images).
 #include "common.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 namespace {
 
@@ -18,63 +22,101 @@ enum { F_NONE = 0, F_GELU = 1, F_RESID = 2, F_PATCH = 3 };
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// C[M,N] = A[M,K] W[N,K]^T + bias, 64 x 64 tile, 256 threads, thread = 4 x 4 outputs, K in steps of 16 through LDS.
+// C[M,N] = A[M,K] W[N,K]^T + bias on the fp32 matrix cores.  Workgroup = 8 waves = a 128 x 192 output tile (every N of the model
+// is a multiple of 192), wave (wm, wn) = rows 32 wm .. + 31 x columns 96 wn .. + 95 = three 32 x 32 accumulator tiles (48 registers).
+// K walks in steps of 32 through ONE LDS stage (A 128 x 32 and W 192 x 32 floats, rows padded to 36 floats: ds_read_b128 of 16
+// rows x 16 bytes is conflict-free); the next stage's 40 KB are requested from global memory before the stage is computed and
+// written behind it, so two workgroups per CU (46 KB, <= 128 VGPRs) hide each other's barriers.
+// Operand order inside a 32-deep stage: a lane holds 4 consecutive k of its row from one 16-byte read and feeds them to 4
+// MFMAs; the lane half h = lane >> 5 takes k = 8c + 4h + s in MFMA s of chunk c -- the SAME map for A and for W, so the products pair
+// up correctly and the summation order (k = 8c + s, then 8c + 4 + s, for s, then c, then stage) is fixed: bit-reproducible.
 //   F_GELU : exact-erf GELU on the result          F_RESID: C += result (in place on the residual stream)
 //   F_PATCH: A is gathered from the NCHW image (row m = image b, patch p; k = c*256 + py*16 + px), the result goes to token
 //            row b*T + 1 + p with the position embedding added (timm PatchEmbed + pos_embed)
+constexpr int GBM = 128, GBN = 192, GBK = 32, GST = GBK + 4;     // GST: LDS row stride in floats
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W,
-                                                       const float* __restrict__ bias, float* __restrict__ C, int ldc, int M, int N, int K,
-                                                       const float* __restrict__ pos) {
-  __shared__ float As[16][64 + 4], Ws[16][64 + 4];
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  float acc[4][4] = {};
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    // stage A (64 x 16) and W (64 x 16), transposed to [k][row]
+__global__ __launch_bounds__(512, 2) void gemm_f32_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, float* __restrict__ C, int ldc, int M, int N,
+                                                              int K, const float* __restrict__ pos) {
+  __shared__ __attribute__((aligned(16))) float As[GBM * GST];
+  __shared__ __attribute__((aligned(16))) float Ws[GBN * GST];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w & 3, wn = w >> 2;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+  // staging: thread t moves 16 bytes of row t / 8 (+ 64 per step), chunk t % 8; 2 steps for A (128 rows), 3 for W (192 rows)
+  const int srow = tid >> 3, sch = tid & 7;
+  const float* a_src[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = tid + q * 256, r = e >> 4, kk = e & 15;
-      const int m = m0 + r, n = n0 + r, k = k0 + kk;
-      float av = 0.f;
-      if (m < M) {
-        if (EPI == F_PATCH) {
-          const int b = m / (T - 1), p = m - b * (T - 1);
-          const int c = k >> 8, py = (k >> 4) & 15, px = k & 15;
-          av = A[(((size_t)b * 3 + c) * 224 + (p / 14) * 16 + py) * 224 + (p % 14) * 16 + px];
-        } else {
-          av = A[(size_t)m * lda + k];
-        }
-      }
-      As[kk][r] = av;
-      Ws[kk][r] = n < N ? W[(size_t)n * K + k] : 0.f;
+  for (int q = 0; q < 2; ++q) {
+    int m = m0 + srow + 64 * q;
+    m = m < M ? m : M - 1;                                         // clamped: rows beyond M are computed and never stored
+    if (EPI == F_PATCH) {
+      const int b = m / (T - 1), pch = m - b * (T - 1);
+      a_src[q] = A + ((size_t)b * 3 * 224 + (pch / 14) * 16) * 224 + (pch % 14) * 16;     // + c*224*224 + py*224 + px
+    } else {
+      a_src[q] = A + (size_t)m * lda;
     }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      const float4 a4 = *(const float4*)&As[kk][ty * 4];
-      const float4 w4 = *(const float4*)&Ws[kk][tx * 4];
-      const float a[4] = {a4.x, a4.y, a4.z, a4.w}, w[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], w[j], acc[i][j]);
-    }
-    __syncthreads();
   }
+  auto load_a = [&](int q, int k0) -> float4 {
+    const int k = k0 + 4 * sch;
+    if (EPI == F_PATCH) return *(const float4*)(a_src[q] + ((size_t)(k >> 8) * 224 + ((k >> 4) & 15)) * 224 + (k & 15));
+    return *(const float4*)(a_src[q] + k);
+  };
+  auto load_w = [&](int q, int k0) -> float4 { return *(const float4*)(W + (size_t)(n0 + srow + 64 * q) * K + k0 + 4 * sch); };
+  float4 pa[2], pw[3];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty * 4 + i;
-    if (m >= M) continue;
+  for (int q = 0; q < 2; ++q) pa[q] = load_a(q, 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + tx * 4 + j;
-      if (n >= N) continue;
-      float v = acc[i][j] + (bias ? bias[n] : 0.f);
+  for (int q = 0; q < 3; ++q) pw[q] = load_w(q, 0);
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += GBK) {
+    __syncthreads();                                               // every wave is done reading the previous stage
+#pragma unroll
+    for (int q = 0; q < 2; ++q) *(float4*)&As[(srow + 64 * q) * GST + 4 * sch] = pa[q];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *(float4*)&Ws[(srow + 64 * q) * GST + 4 * sch] = pw[q];
+    __syncthreads();
+    if (k0 + GBK < K) {                                            // next stage: in flight while this one is computed
+#pragma unroll
+      for (int q = 0; q < 2; ++q) pa[q] = load_a(q, k0 + GBK);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) pw[q] = load_w(q, k0 + GBK);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 a4 = *(const float4*)&As[(32 * wm + l31) * GST + 8 * c + 4 * lh];
+      float4 b4[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) b4[t] = *(const float4*)&Ws[(96 * wn + 32 * t + l31) * GST + 8 * c + 4 * lh];
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const float bv[4] = {b4[t].x, b4[t].y, b4[t].z, b4[t].w};
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sidx], bv[sidx], acc[t], 0, 0, 0);
+        }
+    }
+  }
+  // accumulator tile: column n = lane & 31, row m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): a register is two 128-byte row segments
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int n = n0 + 96 * wn + 32 * t + l31;
+    const float bn = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= M) continue;
+      float v = acc[t][r] + bn;
       if (EPI == F_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));      // exact-erf GELU (timm default)
       if (EPI == F_PATCH) {
-        const int b = m / (T - 1), p = m - b * (T - 1);
-        C[((size_t)b * T + 1 + p) * ldc + n] = v + pos[(size_t)(1 + p) * N + n];
+        const int b = m / (T - 1), pch = m - b * (T - 1);
+        C[((size_t)b * T + 1 + pch) * ldc + n] = v + pos[(size_t)(1 + pch) * N + n];
       } else if (EPI == F_RESID) {
         C[(size_t)m * ldc + n] += v;
       } else {
@@ -102,41 +144,113 @@ __global__ __launch_bounds__(256) void ln_f32_kernel(const float* __restrict__ x
   for (int i = 0; i < 3; ++i) y[(size_t)row * D + lane + 64 * i] = v[i] * rstd * gamma[lane + 64 * i] + beta[lane + 64 * i];
 }
 
-// softmax(q k^T * scale) v for one (image, head): K and V (197 x 64 fp32) in LDS, one thread per query row, online softmax
-__global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, float scale) {
+// softmax(q k^T * scale) v for one (image, head) on the fp32 matrix cores: K and V (224 zero-padded rows x 64 fp32, rows padded to
+// 68 floats) in LDS, wave w owns queries 32w .. 32w + 31.
+//   S^T[key][q] = K Q^T: A = K rows from LDS (one 16-byte read feeds 4 MFMAs), B = the wave's scaled Q rows in 32 registers (lane half h
+//   holds d = 32h + s for step s -- the same map on the K side); seven 32 x 32 accumulator tiles = the whole 224-key column block.
+//   softmax down the accumulator registers of a lane (+ one exchange with lane ^ 32), exact expf, masked beyond T.
+//   O^T[d][q] = V^T P^T: the probabilities ARE the B operand as they stand -- register r of tile kt holds key 32kt + (r&3) + 8(r>>2) + 4h,
+//   so step r contracts over exactly those two keys and the A operand is V[that key][32 dt + lane & 31] (a 128-byte row read per half).
+// Output through a wave-private LDS patch (in the K tile, free behind a barrier) so that rows leave as 256-byte runs.
+constexpr int AKS = HD + 4, ATP = 224, ANW = 7;
+__global__ __launch_bounds__(ANW * 64) void attn_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, float scale) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Ks = sm;
-  float* Vs = sm + T * HD;
+  float* Vs = sm + ATP * AKS;
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
   const int ld = 3 * D;
   const float* base = qkv + (size_t)b * T * ld + h * HD;
-  for (int e = threadIdx.x; e < T * HD; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    Ks[e] = base[(size_t)r * ld + D + c];
-    Vs[e] = base[(size_t)r * ld + 2 * D + c];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int e = tid; e < ATP * 16; e += ANW * 64) {
+    const int r = e >> 4, c = e & 15, rc = r < T ? r : T - 1;
+    float4 kv = *(const float4*)(base + (size_t)rc * ld + D + 4 * c);
+    float4 vv = *(const float4*)(base + (size_t)rc * ld + 2 * D + 4 * c);
+    if (r >= T) { kv = make_float4(0.f, 0.f, 0.f, 0.f); vv = kv; }
+    *(float4*)&Ks[r * AKS + 4 * c] = kv;
+    *(float4*)&Vs[r * AKS + 4 * c] = vv;
+  }
+  const int q0 = 32 * w;
+  const bool active = q0 < T;                           // wave-uniform; inactive waves only keep the barriers company
+  float qv[32];
+  {
+    const int qr = q0 + l31, qc = qr < T ? qr : T - 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 t = *(const float4*)(base + (size_t)qc * ld + 32 * lh + 4 * i);
+      qv[4 * i] = t.x * scale; qv[4 * i + 1] = t.y * scale; qv[4 * i + 2] = t.z * scale; qv[4 * i + 3] = t.w * scale;   // timm scales q first
+    }
   }
   __syncthreads();
-  const int qr = threadIdx.x;
-  if (qr >= T) return;
-  float q[HD], o[HD];
+  f32x16 st[7];
+  float inv_l = 0.f;
+  if (active) {
 #pragma unroll
-  for (int d = 0; d < HD; ++d) { q[d] = base[(size_t)qr * ld + d] * scale; o[d] = 0.f; }      // timm scales q before the product
-  float m = -INFINITY, l = 0.f;
-  for (int key = 0; key < T; ++key) {
-    float s = 0.f;
+    for (int kt = 0; kt < 7; ++kt) {
 #pragma unroll
-    for (int d = 0; d < HD; ++d) s = fmaf(q[d], Ks[key * HD + d], s);
-    const float mn = fmaxf(m, s);
-    const float corr = expf(m - mn), p = expf(s - mn);
-    l = l * corr + p;
+      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) o[d] = fmaf(p, Vs[key * HD + d], o[d] * corr);
-    m = mn;
+      for (int c = 0; c < 8; ++c) {
+        const float4 k4 = *(const float4*)&Ks[(32 * kt + l31) * AKS + 32 * lh + 4 * c];
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, qv[4 * c], st[kt], 0, 0, 0);
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, qv[4 * c + 1], st[kt], 0, 0, 0);
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, qv[4 * c + 2], st[kt], 0, 0, 0);
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, qv[4 * c + 3], st[kt], 0, 0, 0);
+      }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (kt == 6 && key >= T) st[kt][r] = -INFINITY;
+        m = fmaxf(m, st[kt][r]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = expf(st[kt][r] - m);
+        st[kt][r] = p;
+        l += p;
+      }
+    l += __shfl_xor(l, 32);
+    inv_l = 1.f / l;
   }
-  const float inv = 1.f / l;
-  float* dst = out + ((size_t)b * T + qr) * D + h * HD;
+  f32x16 o[2];
 #pragma unroll
-  for (int d = 0; d < HD; ++d) dst[d] = o[d] * inv;
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  if (active) {
+#pragma unroll
+    for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (kt == 6 && 192 + (r & 3) + 8 * (r >> 2) >= T) continue;      // compile-time: both keys of the step are padding (T = 197)
+        const float* vrow = &Vs[(32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh) * AKS + l31];
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], st[kt][r], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], st[kt][r], o[1], 0, 0, 0);
+      }
+  }
+  __syncthreads();                                      // nobody reads the K tile any more: it becomes seven 32 x 68 output patches
+  float* patch = Ks + w * 32 * AKS;
+  if (active) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) patch[l31 * AKS + 32 * dt + (r & 3) + 8 * (r >> 2) + 4 * lh] = o[dt][r] * inv_l;
+    // (same wave writes and reads the patch: the compiler's lgkmcnt wait orders them)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 4 * i + (lane >> 4), qr = q0 + row;
+      const float4 v = *(const float4*)&patch[row * AKS + 4 * (lane & 15)];
+      if (qr < T) *(float4*)(out + ((size_t)b * T + qr) * D + h * HD + 4 * (lane & 15)) = v;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void cls_rows_f32_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ X, int B) {
@@ -148,8 +262,9 @@ __global__ __launch_bounds__(256) void cls_rows_f32_kernel(const float* __restri
 
 template <int EPI>
 int gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, const float* pos, hipStream_t st) {
-  hipLaunchKernelGGL((gemm_f32_kernel<EPI>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, A, lda, W, bias, C, ldc, M, N, K, pos);
-  ROVIT_CHECK_LAUNCH("gemm_f32_kernel");
+  ROVIT_CHECK_ARG(N % GBN == 0 && K % GBK == 0, ROVIT_ERR_SHAPE, "gemm_f32: N must be a multiple of %d and K of %d (got %d, %d)", GBN, GBK, N, K);
+  hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI>), dim3(N / GBN, (M + GBM - 1) / GBM), dim3(512), 0, st, A, lda, W, bias, C, ldc, M, N, K, pos);
+  ROVIT_CHECK_LAUNCH("gemm_f32_mfma_kernel");
   return ROVIT_OK;
 }
 
@@ -182,14 +297,15 @@ extern "C" int rovit_vit_forward_f32(const float* images, const float* const* pa
   hipLaunchKernelGGL(cls_rows_f32_kernel, dim3((batch * D + 255) / 256), dim3(256), 0, st, params[P_CLS], params[P_POS], X, batch);
   ROVIT_CHECK_LAUNCH("cls_rows_f32_kernel");
   RUN(gemm_f32<F_PATCH>(images, 0, params[P_PATCH_W], params[P_PATCH_B], X, D, batch * (T - 1), D, PD, params[P_POS], st));
-  ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)attn_f32_kernel, (size_t)2 * T * HD * 4), ROVIT_ERR_LAUNCH, "vit_forward_f32: cannot raise the LDS limit");
+  const size_t attn_lds = (size_t)2 * ATP * AKS * sizeof(float);
+  ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)attn_f32_mfma_kernel, attn_lds), ROVIT_ERR_LAUNCH, "vit_forward_f32: cannot raise the LDS limit");
   for (int i = 0; i < depth; ++i) {
     const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
     hipLaunchKernelGGL(ln_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, st, X, bp[B_N1W], bp[B_N1B], xn, M, 1, eps);
     ROVIT_CHECK_LAUNCH("ln_f32_kernel");
     RUN(gemm_f32<F_NONE>(xn, D, bp[B_QKVW], bp[B_QKVB], qkv, 3 * D, M, 3 * D, D, nullptr, st));
-    hipLaunchKernelGGL(attn_f32_kernel, dim3(batch * H), dim3(256), (size_t)2 * T * HD * 4, st, qkv, ao, 0.125f);
-    ROVIT_CHECK_LAUNCH("attn_f32_kernel");
+    hipLaunchKernelGGL(attn_f32_mfma_kernel, dim3(batch * H), dim3(ANW * 64), attn_lds, st, qkv, ao, 0.125f);
+    ROVIT_CHECK_LAUNCH("attn_f32_mfma_kernel");
     RUN(gemm_f32<F_RESID>(ao, D, bp[B_PROJW], bp[B_PROJB], X, D, M, D, D, nullptr, st));
     hipLaunchKernelGGL(ln_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, st, X, bp[B_N2W], bp[B_N2B], xn, M, 1, eps);
     ROVIT_CHECK_LAUNCH("ln_f32_kernel");

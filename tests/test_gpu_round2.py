@@ -64,7 +64,9 @@ def test_end_to_end_severity_and_argmax_with_exclusions_counted():
     print(f'kan_severity: {n_cmp} of {B} samples comparable ({int(excluded.sum())} excluded: a layer input crosses the spline cutoff; '
           f'per layer {per_layer}); max |err| comparable {float(sev_err[~excluded].max()) if n_cmp else float("nan"):.4f}, '
           f'excluded {float(sev_err[excluded].max()) if excluded.any() else 0.0:.4f}')
-    assert n_cmp >= 1
+    # round 4: the comparable share is asserted, so the exclusion rate cannot grow unnoticed (measured 18 of 32 = 56 %
+    # at bf16 feature noise 5e-3 RMS over 192 + 64 + 16 spline inputs per sample; the fp32 mode compares every sample)
+    assert n_cmp >= B // 2, (n_cmp, B)
     # kan_severity = 3 sigmoid(spline stack): the feature error is amplified by the stack's slope; measured worst comparable
     # sample 2.3e-2 (one-launch MLP half) / 3.1e-2 (two-launch MLP half, the path batch 32 takes) -> 1.5x the worst case
     assert float(sev_err[~excluded].max()) < 1.5 * BF16_TOL

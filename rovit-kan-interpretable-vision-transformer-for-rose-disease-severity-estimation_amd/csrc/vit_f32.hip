@@ -162,13 +162,17 @@ __global__ __launch_bounds__(ANW * 64) void attn_f32_mfma_kernel(const float* __
   const float* base = qkv + (size_t)b * T * ld + h * HD;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int e = tid; e < ATP * 16; e += ANW * 64) {
-    const int r = e >> 4, c = e & 15, rc = r < T ? r : T - 1;
+  // K goes to LDS now; V is only REQUESTED here (8 x 16 bytes per thread in registers) and written behind the S products, so its
+  // latency hides under the first matrix phase (one workgroup per CU: nothing else would cover it)
+  static_assert(ATP * 16 == 8 * ANW * 64, "8 chunks of a tile per thread");
+  float4 vreg[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = tid + i * ANW * 64, r = e >> 4, c = e & 15, rc = r < T ? r : T - 1;
     float4 kv = *(const float4*)(base + (size_t)rc * ld + D + 4 * c);
-    float4 vv = *(const float4*)(base + (size_t)rc * ld + 2 * D + 4 * c);
-    if (r >= T) { kv = make_float4(0.f, 0.f, 0.f, 0.f); vv = kv; }
+    vreg[i] = *(const float4*)(base + (size_t)rc * ld + 2 * D + 4 * c);
+    if (r >= T) { kv = make_float4(0.f, 0.f, 0.f, 0.f); vreg[i] = kv; }
     *(float4*)&Ks[r * AKS + 4 * c] = kv;
-    *(float4*)&Vs[r * AKS + 4 * c] = vv;
   }
   const int q0 = 32 * w;
   const bool active = q0 < T;                           // wave-uniform; inactive waves only keep the barriers company
@@ -220,6 +224,12 @@ __global__ __launch_bounds__(ANW * 64) void attn_f32_mfma_kernel(const float* __
     l += __shfl_xor(l, 32);
     inv_l = 1.f / l;
   }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = tid + i * ANW * 64;
+    *(float4*)&Vs[(e >> 4) * AKS + 4 * (e & 15)] = vreg[i];
+  }
+  __syncthreads();
   f32x16 o[2];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)

@@ -39,6 +39,9 @@ enum { ROVIT_ACT_NONE = 0, ROVIT_ACT_RELU = 1, ROVIT_ACT_SIGMOID3 = 2 };
 enum { ROVIT_LIN_RELU = 1, ROVIT_LIN_CLAMP10 = 2 };
 /* epilogues of rovit_gemm_nt */
 enum { ROVIT_EPI_BF16 = 0, ROVIT_EPI_GELU = 1, ROVIT_EPI_RESID = 2, ROVIT_EPI_MUL = 3, ROVIT_EPI_PATCH = 4 };
+/* OR-ed into rovit_gemm_nt's `epi`: run the LDS-tiled kernel (128 x 192 / 128 x 96 tiles; the path of shapes the weight-stationary
+ * kernels do not cover) even where a weight-stationary kernel applies -- per call, for tests of that path */
+enum { ROVIT_GEMM_TILED_192 = 0x100, ROVIT_GEMM_TILED_96 = 0x200 };
 
 int rovit_version(void);
 const char* rovit_last_error_string(void);
@@ -126,8 +129,14 @@ int rovit_vit_num_params(int depth);
 size_t rovit_vit_prep_bytes(int depth);
 size_t rovit_vit_workspace_bytes(int batch, int depth, int training);
 int rovit_vit_prepare(const float* const* params, void* prep, int depth, rovit_stream_t stream);
+/* mlp_path: which kernels run the MLP half of every block -- an argument, not library state, because a training step's forward and
+ * backward must agree on it (the one-launch kernels keep act / gelu' / dpre chunk-major, the two-launch kernels row-major): pass the SAME
+ * value to rovit_vit_forward and to the rovit_vit_backward(_notify) calls that consume its workspace.  ROVIT_MLP_AUTO (what the module
+ * passes) selects by size: one launch from 34 000 token rows (batch 173), the measured crossover; the other two values force a path
+ * (parity tests run every batch size through both). */
+enum { ROVIT_MLP_AUTO = 0, ROVIT_MLP_TWO_LAUNCH = 1, ROVIT_MLP_ONE_LAUNCH = 2 };
 int rovit_vit_forward(const float* images, const float* const* params, const void* prep, void* workspace, float* features,
-                      int batch, int depth, int training, rovit_stream_t stream);
+                      int batch, int depth, int training, int mlp_path, rovit_stream_t stream);
 /* forward + explainability taps: attn_taps is a HOST array of `depth` device pointers (bf16 (B*197,192)) that receive
  * each block's attention-module output -- what DeiTTinyBackbone.get_attention_maps collects through forward hooks on
  * `blocks[i].attn` (models/backbone.py:37-62).  prob_taps (optional, like attn_taps): fp32 (B,3,197,197) softmax
@@ -137,7 +146,7 @@ int rovit_vit_forward_taps(const float* images, const float* const* params, cons
 /* images: the batch the forward ran on (read by the patch-embedding weight gradient, which gathers its pixels from it:
  * there is no im2col buffer); may be NULL for ranges with last_block > 0. */
 int rovit_vit_backward(const float* images, const float* d_features, const float* const* params, const void* prep, void* workspace,
-                       float* const* grads, int batch, int depth, int first_block, int last_block, rovit_stream_t stream);
+                       float* const* grads, int batch, int depth, int first_block, int last_block, int mlp_path, rovit_stream_t stream);
 /* fp32 reference-precision forward (inference only; parity / evaluation mode, not the fast path): the same arithmetic
  * with every operand, product and sum in fp32 -- the mode in which BASELINE.json's "logits/severity within 1e-3 (fp32),
  * class argmax bit-exact" is checked end to end.  params: the ORIGINAL fp32 parameters (no prepared weights);
@@ -151,7 +160,7 @@ int rovit_vit_forward_f32(const float* images, const float* const* params, void*
  * gradients; attention_maps.py:24-32 hooks blocks[i].attn): the fused kernels' own buffers, no extra copy.
  *   XHAT1 / XHAT2: bf16 (M,192) normalised rows before the norm1 / norm2 affine; RSTD1 / RSTD2: fp32 (M)
  *   QKV: bf16 (M,576); ATTN_O: bf16 (M,192) attention output before proj; ACT: bf16 gelu(fc1), (M,768) row-major when the
- *   two-launch MLP half ran (batches below rovit_set_mlp_fused_min_rows), CHUNK-MAJOR [24][M][32] when the one-launch half did
+ *   two-launch MLP half ran (mlp_path, see rovit_vit_forward), CHUNK-MAJOR [24][M][32] when the one-launch half did
  *   DQKV: bf16 (M,576) gradient w.r.t. the qkv output of `block`, valid after rovit_vit_backward has processed that
  *   block and before it processes block-2 (call it with first_block = last_block = block, then read) */
 enum { ROVIT_WS_XHAT1 = 0, ROVIT_WS_RSTD1 = 1, ROVIT_WS_QKV = 2, ROVIT_WS_ATTN_O = 3, ROVIT_WS_XHAT2 = 4, ROVIT_WS_RSTD2 = 5,
@@ -162,7 +171,7 @@ int rovit_vit_workspace_field(int batch, int depth, int field, int block, size_t
  * ranges in order down to last_block == 0; that call joins everything into `stream`. */
 int rovit_vit_backward_notify(const float* images, const float* d_features, const float* const* params, const void* prep,
                               void* workspace, float* const* grads, int batch, int depth, int first_block, int last_block,
-                              rovit_stream_t stream, rovit_stream_t notify_stream);
+                              int mlp_path, rovit_stream_t stream, rovit_stream_t notify_stream);
 
 /* ---- the individual backbone kernels (used by rovit_vit_* and exposed for unit tests / profiling) ---------- */
 /* C = A(M,K) W(N,K)^T + bias with a fused epilogue:
@@ -172,12 +181,6 @@ int rovit_vit_backward_notify(const float* images, const float* d_features, cons
 int rovit_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, int epi, void* out,
                   int ldo, void* out2, float* xres, int ldx, const void* mul, int ldm, const float* pos, int tokens,
                   rovit_stream_t stream);
-/* First half of the MLP backward with gelu' recomputed (autograd of timm Mlp: fc2, GELU; reference reached through
- * models/backbone.py:12-25 and training/trainer.py:119,136):
- *   dpre (M,768) = (dY (M,192) W2T (768,192)^T) * gelu'( bf16( H (M,192) W1 (768,192)^T + b1 ) )
- * H = xhat2 (the fc1 input), W1/b1 the fc1 weight with the norm2 affine folded in, W2T the transposed fc2 weight. */
-int rovit_gemm_mlp_bwd(const void* dY, int ldy, const void* H, int ldh, const void* W2T, const void* W1, const float* b1, int M,
-                       void* dpre, int ldo, rovit_stream_t stream);
 /* X(M,192) += bf16(A W^T + bias), fused with the LayerNorm that follows the residual add (timm Block: x = x + f(x);
  * norm(x)): xhat_out bf16 (M,192) and rstd_out (M) of the updated rows; xhat_out NULL = residual add only. */
 int rovit_gemm_resid_ln(const void* A, int lda, const void* W, int ldw, int M, int K, const float* bias, float* X, void* xhat_out,
@@ -211,12 +214,6 @@ int rovit_mlp_prepare_stream_tail(const void* w1f, const void* w2, const void* w
 int rovit_block_tail_fwd(const void* o, const void* wstream, const float* bp, const float* b1, const float* b2, float* X, void* xhat2,
                          float* rstd2, void* act, void* dact, void* xhat_out, float* rstd_out, const float* bq_next, void* qkv_next,
                          float eps, int M, int act_rows, rovit_stream_t stream);
-/* ... and the backward's counterpart: rovit_mlp_fused_bwd with the norm2 backward in registers and, behind it, the proj dgrad
- * dO (M,192) = dXb Wproj in the same launch (dO NULL: none).  wstream_bwd from rovit_mlp_prepare_stream_tail_bwd(W2T, W1T folded,
- * WprojT = the transposed bf16 proj weight). */
-int rovit_mlp_prepare_stream_tail_bwd(const void* w2T, const void* w1T, const void* wprojT, void* wstream, rovit_stream_t stream);
-int rovit_block_tail_bwd(const void* dY, const void* wstream_bwd, const void* dact, void* dpre, const void* xhat2, const float* rstd2,
-                         float* dX, void* dXb, void* dO, int M, rovit_stream_t stream);
 /* The dgrad chain of the same half in ONE launch (autograd of the above, training/trainer.py:119,136):
  *   dpre (M,768) = (dY (M,192) W2T^T) * dact        -- kept: the fc1 weight gradient reads it (bit-identical to rovit_gemm_nt(ROVIT_EPI_MUL))
  *   dX (M,192) += rstd2 (g - mean(g) - xhat2 mean(g xhat2)),  g = dpre W1T^T;   dXb = bf16(dX)     (= rovit_gemm_ln_bwd)
@@ -224,25 +221,10 @@ int rovit_block_tail_bwd(const void* dY, const void* wstream_bwd, const void* da
  * dact (input) and dpre (output) are chunk-major [24][M][32] like the forward's act / dact; rovit_wgrad_multi_ex reads them as such. */
 int rovit_mlp_fused_bwd(const void* dY, const void* wstream_bwd, const void* dact, void* dpre, const void* xhat2, const float* rstd2,
                         float* dX, void* dXb, int M, rovit_stream_t stream);
-/* developer knob (timing ablations of the lockstep fused MLP kernels: bit 0 skip the row-wise epilogue, 1 skip GELU, 2 skip fc2, 3 skip fc1; results are then wrong) */
-int rovit_set_mlp_debug(int bits);
-/* token rows (batch x 197) from which rovit_vit_forward / rovit_vit_backward use rovit_mlp_fused_fwd / _bwd instead of the two-launch
- * MLP half (default 34000 = batch 173, the measured crossover; environment ROVIT_MLP_FUSED_MIN_ROWS); 0 = always fused */
-int rovit_set_mlp_fused_min_rows(int rows);
-/* developer knob (A/B timing): schedule of rovit_mlp_fused_fwd, 8 = one 256-row workgroup of 8 waves per CU in lockstep, 4 = two 128-row
- * ones, 9 = 8 waves with waves 4-7 staggered half a chunk behind waves 0-3, 10 = 8 waves, in-wave software pipeline (fc1 of chunk
- * j under the GELU of chunk j - 1) with the GELU looked up in an LDS table of the bf16 input patterns (DEFAULT) */
-int rovit_set_mlp_waves(int waves);
 /* dgrad through a Linear that follows a LayerNorm, fused with that LayerNorm's backward:
  * dxhat = dY W^T;  dX += rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat));  dXb = bf16(dX) */
 int rovit_gemm_ln_bwd(const void* dY, int ldy, const void* W, int ldw, int M, int K, const void* xhat, const float* rstd, float* dX,
                       void* dXb, rovit_stream_t stream);
-/* developer knob: output tile (tn x tk) of the weight-gradient kernel for A/B timing; 0,0 = library default per shape */
-int rovit_set_wgrad_tile(int tn, int tk);
-int rovit_set_gemm_debug(int flags); /* developer knob for timing ablations (tools/exp_*.py): bit 0 skip epilogue stores, bit 1 skip
-                                       MFMAs, bit 2 skip steady-state LDS-DMA loads, bit 3 skip the GELU math; bits 4-5 = bits 0-1
-                                       for the weight-gradient kernel.  Results are wrong with any bit set. */
-int rovit_set_gemm_tile(int tile); /* tuning knob: 0 = 128x192 tiles where N allows, 1 = 128x96 */
 /* G(N,K) = dY(M,N)^T A(M,K) and colsum(dY), split over M into `splits` fp32 slabs inside ws */
 int rovit_wgrad_splits(int M, int N, int K);
 size_t rovit_wgrad_workspace_bytes(int N, int K, int splits);

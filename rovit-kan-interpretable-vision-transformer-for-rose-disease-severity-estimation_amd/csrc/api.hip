@@ -14,7 +14,8 @@ void rovit_set_error(const char* fmt, ...) {
 
 // 100: round 1.  200: round 2 changed rovit_vit_backward(_notify) (leading `images`) and rovit_joint_loss (float severity targets).
 // 300: round 3 adds the fused MLP entry points and the prepared-weight stream they read (rovit_vit_prep_bytes grew).
-extern "C" int rovit_version(void) { return 303; }
+// 400: round 4 -- rovit_vit_forward / _backward(_notify) take `mlp_path`; every rovit_set_* knob and the experiments that lost left the ABI.
+extern "C" int rovit_version(void) { return 400; }
 extern "C" const char* rovit_last_error_string(void) { return g_err; }
 
 #include <mutex>
@@ -35,8 +36,21 @@ bool rovit_set_max_lds(const void* fn, size_t bytes) {
 }
 
 #ifdef ROVIT_DEV
+#include <stdlib.h>
+#include <string.h>
 int g_rovit_knob[ROVIT_KNOB_COUNT] = {0};
 bool g_rovit_knob_set[ROVIT_KNOB_COUNT] = {false};
+// ROVIT_DEV_KNOBS="id=value,id=value" (the developer library's ONE environment variable), read when the library is loaded
+static int g_rovit_knob_env = [] {
+  const char* e = getenv("ROVIT_DEV_KNOBS");
+  while (e && *e) {
+    int id = -1, v = 0, n = 0;
+    if (sscanf(e, "%d=%d%n", &id, &v, &n) == 2 && id >= 0 && id < ROVIT_KNOB_COUNT) { g_rovit_knob[id] = v; g_rovit_knob_set[id] = true; }
+    e = strchr(e, ',');
+    if (e) ++e;
+  }
+  return 0;
+}();
 // developer library only (make dev): override / clear (value < 0 with clear != 0) a knob of common.h's RovitKnob list
 extern "C" int rovit_dev_set_knob(int id, int value, int clear) {
   ROVIT_CHECK_ARG(id >= 0 && id < ROVIT_KNOB_COUNT, ROVIT_ERR_SHAPE, "dev knob %d out of range", id);

@@ -21,7 +21,7 @@ namespace {
 #ifdef ROVIT_DEV
 #define ATTN_DBG(a, bit) ((a).dbg & (bit))
 #else
-#define ATTN_DBG(a, bit) false      // the product kernels have no skip-work path
+#define ATTN_DBG(a, bit) (false)    // the product kernels have no skip-work path
 #endif
 
 constexpr int HD = 64;               // head dim

@@ -51,6 +51,16 @@ enum RovitKnob {
   ROVIT_KNOB_ATTN_BWD_R3 = 1,   // 1: round 3's attention backward (one workgroup per CU, four LDS tiles)
   ROVIT_KNOB_ATTN_DBG = 2,      // attention backward ablation bits (skip pass 1 / pass 2; results are then wrong)
   ROVIT_KNOB_ATTN_BWD_SPLIT = 3, // 1: attention backward with the two passes as separate workgroups (measured slower: 62 us against 50)
+  ROVIT_KNOB_SINGLE_STREAM = 4,  // 1: forward and backward entirely on the caller's stream (serial per-kernel times for the profiles)
+  ROVIT_KNOB_WGRAD_SPLITS = 5,   // M-splits of the merged weight-gradient launch (default 16)
+  ROVIT_KNOB_GEMM_DBG = 6,       // GEMM / weight-gradient ablation bits (skip stores / MFMAs / loads; results are then wrong)
+  ROVIT_KNOB_MLP_DBG = 7,        // fused-MLP ablation bits (skip epilogue / GELU / fc2 / fc1; results are then wrong)
+  ROVIT_KNOB_MLP_SCHEDULE = 8,   // fused MLP forward: 10 (default) in-wave pipeline + GELU table, 8 lockstep, 9 staggered, 4 two 128-row workgroups
+  ROVIT_KNOB_MLP_RPW = 9,        // token rows per workgroup of the 8-wave MLP kernels (default: by size, 240 or 256)
+  ROVIT_KNOB_WGRAD_TILE = 10,    // (tn << 16) | tk: output tile of the single-problem weight-gradient launch
+  ROVIT_KNOB_WGRAD_WGS = 11,     // workgroups the single-problem weight-gradient launch aims for (default 512)
+  ROVIT_KNOB_KAN_MFMA_NS = 12,   // sample tiles per wave of the matrix-core KAN stack (default: by grid size)
+  ROVIT_KNOB_KDMA = 13,          // 0: the register-staged kernels instead of gemm_kdma_kernel for the K = 576 dgrad
   ROVIT_KNOB_COUNT = 32
 };
 #ifdef ROVIT_DEV

@@ -26,6 +26,14 @@
 #include <type_traits>
 #include "common.h"
 
+#ifdef ROVIT_DEV
+#define GEMM_DBG(g, bit) ((g).dbg & (bit))
+#define GEMM_SET_DBG(g, v) (g).dbg = (v)
+#else
+#define GEMM_DBG(g, bit) (false)    // the product kernels have no skip-work path
+#define GEMM_SET_DBG(g, v) ((void)0)
+#endif
+
 namespace {
 
 inline bool set_max_lds(const void* fn, size_t bytes) { return rovit_set_max_lds(fn, bytes); }
@@ -49,7 +57,9 @@ struct GemmArgs {
   int n_tiles;
   float* rstd_out; float eps;   // EPI_RESID_LN: statistics of the LayerNorm fused behind the residual add
   const float* img;   // EPI_PATCH_IMG: images (B,3,224,224) fp32; row m = (image, patch), column = c*256 + kh*16 + kw
-  int dbg;            // developer knob, see rovit_set_gemm_debug (bit 0 skip epilogue stores, 1 skip MFMAs, 2 skip DMA, 3 skip GELU)
+#ifdef ROVIT_DEV
+  int dbg;            // developer library only (ROVIT_KNOB_GEMM_DBG): bit 0 skip epilogue stores, 1 skip MFMAs, 2 skip DMA, 3 skip GELU
+#endif
 };
 
 // gelu_and_grad / gelu_grad: common.h (shared with mlp_fused.hip)
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(256 * WK, 2) void gemm_ws_kernel(const GemmArgs g, 
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(wf[j][ks], af[i], acc[i][j]);     // D[n][m]
     }
-    const int mbase = (g.dbg & 1) ? g.M : (tile0 + t) * BM;
+    const int mbase = GEMM_DBG(g, 1) ? g.M : (tile0 + t) * BM;
     constexpr bool STAGED = (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_MUL || EPI == EPI_RESID_LN || EPI == EPI_LNBWD);
     constexpr bool ROWWISE = (EPI == EPI_RESID_LN || EPI == EPI_LNBWD);
     if (WK == 2) {
@@ -633,8 +643,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_dma_kernel(const GemmArgs g, i
     }
   };
   dma(tile0, 0);
-  if (ntile > 1 && !(g.dbg & 4)) dma(tile0 + 1, 1);
-  if (ntile > 2 && !(g.dbg & 4)) dma(tile0 + 2, 2);
+  if (ntile > 1 && !GEMM_DBG(g, 4)) dma(tile0 + 1, 1);
+  if (ntile > 2 && !GEMM_DBG(g, 4)) dma(tile0 + 2, 2);
 
   // stationary W fragments + bias (loaded once; nothing else is loaded from global memory inside the loop)
   bf16x8 wf[3][KS];
@@ -668,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_dma_kernel(const GemmArgs g, i
       wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();                     // every wave's pieces of tile t are in; tile t-1 fully retired
-    if (t >= 1 && t + 2 < ntile && !(g.dbg & 4)) dma(tile0 + t + 2, (t + 2) % 3);     // refill the slot tile t-1 used
+    if (t >= 1 && t + 2 < ntile && !GEMM_DBG(g, 4)) dma(tile0 + t + 2, (t + 2) % 3);     // refill the slot tile t-1 used
 
     f32x4 acc[TM][3];
 #pragma unroll
@@ -676,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_dma_kernel(const GemmArgs g, i
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc[i][j] = bias4[j];
     const bf16* Ac = lds + slot * SLOT + frag_row;
-    if (!(g.dbg & 2))
+    if (!GEMM_DBG(g, 2))
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       bf16x8 af[TM];
@@ -698,7 +708,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_dma_kernel(const GemmArgs g, i
         *(bf16x4*)(Cs + (i * 16 + cw_row) * K + phys * 8 + 4 * (lg & 1)) = pack4(acc[i][j]);
       }
     barrier_lds();
-    const int mbase = (g.dbg & 1) ? g.M : (tile0 + t) * BM;
+    const int mbase = GEMM_DBG(g, 1) ? g.M : (tile0 + t) * BM;
 #pragma unroll
     for (int q = 0; q < BM * 24 / NT; ++q) {
       const int c = tid + q * NT;
@@ -708,7 +718,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_dma_kernel(const GemmArgs g, i
         const int phys = (ch & ~7) | ((ch & 7) ^ (row & 7));
         const bf16x8 pv = *(const bf16x8*)(Cs + row * K + phys * 8);
         const size_t o = (size_t)m * g.ldo + n0 + ch * 8;
-        if (EPI == EPI_BF16 || (EPI == EPI_GELU && (g.dbg & 8))) {
+        if (EPI == EPI_BF16 || (EPI == EPI_GELU && GEMM_DBG(g, 8))) {
           *(bf16x8*)(g.out + o) = pv;
           if (EPI == EPI_GELU && g.out2) *(bf16x8*)(g.out2 + o) = pv;
         } else if (EPI == EPI_MUL) {
@@ -1131,8 +1141,8 @@ int launch_kdma(const GemmArgs& g0, hipStream_t st) {
 }
 // the K = 768 instantiation needs 96 registers of stationary W per lane and spills at the 168-register budget of a
 // 12-wave workgroup: off unless ROVIT_KDMA768=1
-static bool kdma_k768() { static const bool on = getenv("ROVIT_KDMA768") && getenv("ROVIT_KDMA768")[0] == '1'; return on; }
-static bool kdma_enabled() { static const bool on = !(getenv("ROVIT_KDMA") && getenv("ROVIT_KDMA")[0] == '0'); return on; }
+// (the K = 768 instantiation of gemm_kdma_kernel reads 590 KB of LDS fragments per tile and spills at the 168-register budget: slower, not built)
+static bool kdma_enabled() { return ROVIT_KNOB(ROVIT_KNOB_KDMA, 1) != 0; }
 
 template <int BM, int BN, int WM, int WN>
 int launch_nt(const GemmArgs& g0, int epi, hipStream_t st) {
@@ -1193,7 +1203,9 @@ struct WgradArgs {
   int splits, rows_per_split, tiles_per_split;
   int patch_tokens;     // >0 (single problem only): dY row of m is m + m/(T-1) + 1 (skip each image's cls row)
   const float* img;     // PATCH only: when set, the A operand (patch pixels, K = 768) is gathered from these fp32 NCHW images
-  int dbg;              // developer knob: bit 0 skip steady-state global loads, bit 1 skip MFMAs
+#ifdef ROVIT_DEV
+  int dbg;              // developer library only (ROVIT_KNOB_GEMM_DBG >> 4): bit 0 skip steady-state global loads, bit 1 skip MFMAs
+#endif
 };
 
 // Output tile TN (columns of dY = rows n of G) x TK (columns of A = columns k of G) per workgroup; four waves as 2 (k) x 2 (n),
@@ -1382,13 +1394,13 @@ __global__ __launch_bounds__(128 * WN) void wgrad_kernel(const WgradArgs g) {
   for (int s = 0; s < nsteps; s += 2) {
     const int mb = m_begin + s * WG_MSTEP;
     if (s + 1 < nsteps) store(1, mb + WG_MSTEP, ryA, raA);
-    if (!(g.dbg & 1)) load(mb + 3 * WG_MSTEP, ryA, raA);
-    if (!(g.dbg & 2)) compute(0);
+    if (!GEMM_DBG(g, 1)) load(mb + 3 * WG_MSTEP, ryA, raA);
+    if (!GEMM_DBG(g, 2)) compute(0);
     barrier_lds();
     if (s + 1 < nsteps) {
       if (s + 2 < nsteps) store(0, mb + 2 * WG_MSTEP, ryB, raB);
-      if (!(g.dbg & 1)) load(mb + 4 * WG_MSTEP, ryB, raB);
-      if (!(g.dbg & 2)) compute(1);
+      if (!GEMM_DBG(g, 1)) load(mb + 4 * WG_MSTEP, ryB, raB);
+      if (!GEMM_DBG(g, 2)) compute(1);
       barrier_lds();
     }
   }
@@ -1494,11 +1506,7 @@ __global__ __launch_bounds__(256) void wgrad_affine_finalize_kernel(const Reduce
 
 }  // namespace
 
-static int g_gemm_dbg = 0;
-extern "C" int rovit_set_gemm_debug(int d) { g_gemm_dbg = d; return ROVIT_OK; }
 void rovit_set_cu_budget(int cus) { g_cu_budget = cus < 8 ? 8 : (cus > 256 ? 256 : cus); }
-static int g_gemm_tile = 0;      // 0: weight-stationary kernel where it applies, 2: tiled 128x192, 3: tiled 128x96
-extern "C" int rovit_set_gemm_tile(int t) { g_gemm_tile = t; return ROVIT_OK; }
 
 extern "C" int rovit_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, int epi,
                              void* out, int ldo, void* out2, float* xres, int ldx, const void* mul, int ldm,
@@ -1511,7 +1519,9 @@ extern "C" int rovit_gemm_nt(const void* A, int lda, const void* W, int ldw, int
   GemmArgs g{};
   g.A = (const bf16*)A; g.lda = lda; g.W = (const bf16*)W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias;
   g.out = (bf16*)out; g.ldo = ldo; g.out2 = (bf16*)out2; g.xres = xres; g.ldx = ldx; g.mul = (const bf16*)mul; g.ldm = ldm;
-  g.pos = pos; g.tokens = tokens; g.dbg = g_gemm_dbg;
+  g.pos = pos; g.tokens = tokens; GEMM_SET_DBG(g, ROVIT_KNOB(ROVIT_KNOB_GEMM_DBG, 0));
+  const int tiled = epi & (ROVIT_GEMM_TILED_192 | ROVIT_GEMM_TILED_96);       // per-call: force the LDS-tiled kernels (tests of that path)
+  epi &= 0xff;
   switch (epi) {
     case EPI_BF16: case EPI_GELU: ROVIT_CHECK_ARG(out && ldo % 4 == 0, ROVIT_ERR_NULL, "gemm_nt: bf16 output missing"); break;
     case EPI_RESID: ROVIT_CHECK_ARG(xres && ldx % 4 == 0, ROVIT_ERR_NULL, "gemm_nt: residual stream missing"); break;
@@ -1519,20 +1529,15 @@ extern "C" int rovit_gemm_nt(const void* A, int lda, const void* W, int ldw, int
     case EPI_PATCH: ROVIT_CHECK_ARG(xres && pos && tokens > 1 && M % (tokens - 1) == 0, ROVIT_ERR_SHAPE, "gemm_nt: bad patch epilogue"); break;
     default: ROVIT_CHECK_ARG(false, ROVIT_ERR_SHAPE, "gemm_nt: unknown epilogue %d", epi);
   }
-  if (g_gemm_tile == 0 && N % 192 == 0) {
+  if (!tiled && N % 192 == 0) {
     if (K == 192 && epi == EPI_BF16) return launch_ws_dma<EPI_BF16>(g, (hipStream_t)stream);
     if (K == 192 && epi == EPI_GELU) return launch_ws_dma<EPI_GELU>(g, (hipStream_t)stream);
-    if (K == 192 && epi == EPI_MUL && !getenv("ROVIT_MUL_NO_DMA")) return launch_ws_dma<EPI_MUL>(g, (hipStream_t)stream);
+    if (K == 192 && epi == EPI_MUL) return launch_ws_dma<EPI_MUL>(g, (hipStream_t)stream);
     if (K == 192) return launch_ws<6, 1, 64>(g, epi, (hipStream_t)stream);
     if (K == 576) return launch_ws<9, 2, 32>(g, epi, (hipStream_t)stream);
     if (K == 768) return launch_ws<12, 2, 32>(g, epi, (hipStream_t)stream);
   }
-  if (g_gemm_tile == 1 && N % 192 == 0 && (K == 192 || K == 576 || K == 768)) {      // register-staged weight-stationary kernel
-    if (K == 192) return launch_ws<6, 1, 64>(g, epi, (hipStream_t)stream);
-    if (K == 576) return launch_ws<9, 2, 32>(g, epi, (hipStream_t)stream);
-    return launch_ws<12, 2, 32>(g, epi, (hipStream_t)stream);
-  }
-  if (g_gemm_tile <= 2 && N % 192 == 0) return launch_nt<128, 192, 2, 2>(g, epi, (hipStream_t)stream);
+  if (!(tiled & ROVIT_GEMM_TILED_96) && N % 192 == 0) return launch_nt<128, 192, 2, 2>(g, epi, (hipStream_t)stream);
   return launch_nt<128, 96, 2, 2>(g, epi, (hipStream_t)stream);
 }
 
@@ -1547,10 +1552,11 @@ extern "C" int rovit_patch_embed_fwd(const float* images, const void* W, const f
                   "patch_embed_fwd: buffers must be 16-byte aligned");
   GemmArgs g{};
   g.A = nullptr; g.lda = 768; g.W = (const bf16*)W; g.ldw = 768; g.M = batch * 196; g.N = 192; g.K = 768; g.bias = bias;
-  g.xres = X; g.ldx = 192; g.pos = pos; g.tokens = tokens; g.img = images; g.dbg = g_gemm_dbg;
+  g.xres = X; g.ldx = 192; g.pos = pos; g.tokens = tokens; g.img = images; GEMM_SET_DBG(g, ROVIT_KNOB(ROVIT_KNOB_GEMM_DBG, 0));
   return launch_ws<12, 2, 32>(g, EPI_PATCH_IMG, (hipStream_t)stream);
 }
 
+#ifdef ROVIT_DEV      // round 2's memory mode (gelu' recomputed by the backward: 64 us against 40): developer library only
 // dpre = (dY W2T^T) * gelu'(bf16(H W1^T + b1)): first half of the MLP backward with gelu' recomputed from xhat2
 // (reference arithmetic: autograd of timm Mlp, fc2 then GELU then fc1)
 extern "C" int rovit_gemm_mlp_bwd(const void* dY, int ldy, const void* H, int ldh, const void* W2T, const void* W1, const float* b1,
@@ -1565,23 +1571,16 @@ extern "C" int rovit_gemm_mlp_bwd(const void* dY, int ldy, const void* H, int ld
   // weights per lane and spills at the 168-register budget of 3 waves per SIMD (102 us): not instantiated
   return launch_mlp_bwd<64, 12>(g, (hipStream_t)stream);
 }
+#endif
 
 extern "C" size_t rovit_wgrad_workspace_bytes(int N, int K, int splits) {
   return ((size_t)splits * N * K + (size_t)splits * N) * sizeof(float);
 }
 
-// Tile choice.  tile id = (TN << 16) | TK; 0 = the library's default for the shape.  Developer knob (A/B timing only):
-// rovit_set_wgrad_tile(tn, tk), environment ROVIT_WGRAD_TILE=tn,tk.
-static int g_wgrad_tile = [] {
-  const char* e = getenv("ROVIT_WGRAD_TILE");
-  int tn = 0, tk = 0;
-  if (e && sscanf(e, "%d,%d", &tn, &tk) == 2) return (tn << 16) | tk;
-  return 0;
-}();
-extern "C" int rovit_set_wgrad_tile(int tn, int tk) { g_wgrad_tile = (tn << 16) | tk; return ROVIT_OK; }
-
+// Tile of the single-problem launch: 96 x 96 (developer library: ROVIT_KNOB_WGRAD_TILE = (tn << 16) | tk for A/B timing).
 static void wgrad_tile_for(int N, int K, int* tn, int* tk) {
-  int n = g_wgrad_tile >> 16, k = g_wgrad_tile & 0xffff;
+  const int knob = ROVIT_KNOB(ROVIT_KNOB_WGRAD_TILE, 0);
+  int n = knob >> 16, k = knob & 0xffff;
   if (n <= 0 || k <= 0 || N % n || K % k) { n = 96; k = 96; }
   *tn = n; *tk = k;
 }
@@ -1590,7 +1589,7 @@ extern "C" int rovit_wgrad_splits(int M, int N, int K) {
   int tn, tk;
   wgrad_tile_for(N, K, &tn, &tk);
   const int tiles = (N / tn) * (K / tk);
-  static const int target = getenv("ROVIT_WGRAD_WGS") ? atoi(getenv("ROVIT_WGRAD_WGS")) : 512;
+  const int target = ROVIT_KNOB(ROVIT_KNOB_WGRAD_WGS, 512);
   int s = (target + tiles - 1) / tiles;            // ~2 workgroups per CU: measured best trade against slab traffic
   s = (s + 7) / 8 * 8;
   const int max_s = (M + WG_MSTEP - 1) / WG_MSTEP;
@@ -1631,18 +1630,20 @@ extern "C" int rovit_wgrad(const void* dY, int ldy, const void* A, int lda, int 
   g.splits = splits;
   g.rows_per_split = ((M + splits - 1) / splits + WG_MSTEP - 1) / WG_MSTEP * WG_MSTEP;
   g.patch_tokens = patch_tokens;
-  g.dbg = g_gemm_dbg >> 4;
+  GEMM_SET_DBG(g, ROVIT_KNOB(ROVIT_KNOB_GEMM_DBG, 0) >> 4);
   // a split whose first row is past M still writes zeros, so the reduce can sum every slab
   int tn, tk;
   wgrad_tile_for(N, K, &tn, &tk);
   hipStream_t st = (hipStream_t)stream;
   switch ((tn << 16) | tk) {
     case (96 << 16) | 96: launch_wgrad<96, 96>(g, st); break;
+#ifdef ROVIT_DEV      // tile sweep of round 2 (profiles/r02_wgrad_tile_sweep.txt)
     case (64 << 16) | 96: launch_wgrad<64, 96>(g, st); break;
     case (96 << 16) | 64: launch_wgrad<96, 64>(g, st); break;
     case (64 << 16) | 64: launch_wgrad<64, 64>(g, st); break;
     case (96 << 16) | 192: launch_wgrad<96, 192>(g, st); break;
     case (192 << 16) | 96: launch_wgrad<192, 96>(g, st); break;
+#endif
     default: rovit_set_error("wgrad: no kernel for tile %d x %d", tn, tk); return ROVIT_ERR_SHAPE;
   }
   ROVIT_CHECK_LAUNCH("wgrad_kernel");
@@ -1666,7 +1667,7 @@ extern "C" int rovit_patch_embed_wgrad(const void* dY, int ldy, const float* ima
   g.rows_per_split = ((M + splits - 1) / splits + WG_MSTEP - 1) / WG_MSTEP * WG_MSTEP;
   g.patch_tokens = tokens;
   g.img = images;
-  g.dbg = g_gemm_dbg >> 4;
+  GEMM_SET_DBG(g, ROVIT_KNOB(ROVIT_KNOB_GEMM_DBG, 0) >> 4);
   // 192-wide output tiles when N allows: the fp32 pixels (twice the bytes of a bf16 im2col row) are then read by one
   // workgroup per M-split instead of two (61.6 -> 56.3 us at batch 256)
   if (N % 192 == 0) launch_wgrad<192, 96>(g, (hipStream_t)stream);
@@ -1692,7 +1693,7 @@ int rovit_wgrad_batch(const RovitWgradDesc* descs, int n, int M, int splits, rov
   g.M = M;
   g.splits = splits;
   g.rows_per_split = ((M + splits - 1) / splits + WG_MSTEP - 1) / WG_MSTEP * WG_MSTEP;
-  g.dbg = g_gemm_dbg >> 4;
+  GEMM_SET_DBG(g, ROVIT_KNOB(ROVIT_KNOB_GEMM_DBG, 0) >> 4);
   // a lone problem (the qkv weight gradient flushed at the end of a data-parallel block range): 96 x 96 tiles give twice the
   // workgroups for the same 16 M-splits (96 -> 192); every element still sums the same rows in the same order, so the
   // result is bit-identical to the merged launch's
@@ -1700,16 +1701,12 @@ int rovit_wgrad_batch(const RovitWgradDesc* descs, int n, int M, int splits, rov
   // columns instead of 64-96, so the L2 -> CU re-read traffic of the launch halves (the per-CU load path, not HBM, bounded the
   // smaller tiles: DESIGN.md "weight gradients").  12 tiles per M-split; 16 splits = 192 workgroups in the step (the other
   // stream's dgrad kernels keep the remaining CUs busy), 21 = 252 is the fastest standalone (73 us against 107 us for 64 x 192
-  // tiles x 14 splits on the same box).  ROVIT_WGRAD_MERGE_TN=64 / 96: the earlier four-wave tiles.
-  static const int merge_tn = getenv("ROVIT_WGRAD_MERGE_TN") ? atoi(getenv("ROVIT_WGRAD_MERGE_TN")) : 192;
+  // tiles x 14 splits on the same box).
   if (n == 1 && g.p[0].K % 96 == 0) launch_wgrad<96, 96>(g, (hipStream_t)stream);
-  else if (merge_tn == 192) {        // 192 x 192 tiles, eight waves: 12 tiles per split
-    for (int j = 0; j < n; ++j) ROVIT_CHECK_ARG(descs[j].N % 192 == 0, ROVIT_ERR_SHAPE, "wgrad_batch: N %% 192 for 192-wide tiles");
+  else {                             // 192 x 192 tiles, eight waves: 12 tiles per split
+    for (int j = 0; j < n; ++j) ROVIT_CHECK_ARG(descs[j].N % 192 == 0 && descs[j].K % 192 == 0, ROVIT_ERR_SHAPE, "wgrad_batch: N, K %% 192 for 192-wide tiles");
     launch_wgrad<192, 192, 4>(g, (hipStream_t)stream);
-  } else if (merge_tn == 64) {
-    for (int j = 0; j < n; ++j) ROVIT_CHECK_ARG(descs[j].N % 64 == 0, ROVIT_ERR_SHAPE, "wgrad_batch: N %% 64 for 64-wide tiles");
-    launch_wgrad<64, 192>(g, (hipStream_t)stream);
-  } else launch_wgrad<96, 192>(g, (hipStream_t)stream);
+  }
   ROVIT_CHECK_LAUNCH("wgrad_kernel (batch)");
   return ROVIT_OK;
 }
@@ -1786,9 +1783,9 @@ extern "C" int rovit_gemm_resid_ln(const void* A, int lda, const void* W, int ld
   ROVIT_CHECK_ARG(!xhat_out || rstd_out, ROVIT_ERR_NULL, "gemm_resid_ln: rstd_out missing");
   GemmArgs g{};
   g.A = (const bf16*)A; g.lda = lda; g.W = (const bf16*)W; g.ldw = ldw; g.M = M; g.N = 192; g.K = K; g.bias = bias;
-  g.xres = X; g.ldx = 192; g.out = (bf16*)xhat_out; g.ldo = 192; g.rstd_out = rstd_out; g.eps = eps; g.dbg = g_gemm_dbg;
+  g.xres = X; g.ldx = 192; g.out = (bf16*)xhat_out; g.ldo = 192; g.rstd_out = rstd_out; g.eps = eps; GEMM_SET_DBG(g, ROVIT_KNOB(ROVIT_KNOB_GEMM_DBG, 0));
   if (K == 192) return launch_ws<6, 1, 64>(g, EPI_RESID_LN, (hipStream_t)stream);
-  if (kdma_enabled() && xhat_out && (K == 576 || kdma_k768())) return K == 576 ? launch_kdma<18, EPI_RESID_LN>(g, (hipStream_t)stream) : launch_kdma<24, EPI_RESID_LN>(g, (hipStream_t)stream);
+  if (kdma_enabled() && xhat_out && K == 576) return launch_kdma<18, EPI_RESID_LN>(g, (hipStream_t)stream);
   if (K == 576) return launch_ws<9, 2, 32>(g, EPI_RESID_LN, (hipStream_t)stream);
   return launch_ws<12, 2, 32>(g, EPI_RESID_LN, (hipStream_t)stream);
 }
@@ -1803,9 +1800,9 @@ extern "C" int rovit_gemm_ln_bwd(const void* dY, int ldy, const void* W, int ldw
                   "gemm_ln_bwd: alignment");
   GemmArgs g{};
   g.A = (const bf16*)dY; g.lda = ldy; g.W = (const bf16*)W; g.ldw = ldw; g.M = M; g.N = 192; g.K = K;
-  g.mul = (const bf16*)xhat; g.ldm = 192; g.pos = rstd; g.xres = dX; g.ldx = 192; g.out = (bf16*)dXb; g.ldo = 192; g.dbg = g_gemm_dbg;
+  g.mul = (const bf16*)xhat; g.ldm = 192; g.pos = rstd; g.xres = dX; g.ldx = 192; g.out = (bf16*)dXb; g.ldo = 192; GEMM_SET_DBG(g, ROVIT_KNOB(ROVIT_KNOB_GEMM_DBG, 0));
   if (K == 192) return launch_ws<6, 1, 64>(g, EPI_LNBWD, (hipStream_t)stream);
-  if (kdma_enabled() && (K == 576 || kdma_k768())) return K == 576 ? launch_kdma<18, EPI_LNBWD>(g, (hipStream_t)stream) : launch_kdma<24, EPI_LNBWD>(g, (hipStream_t)stream);
+  if (kdma_enabled() && K == 576) return launch_kdma<18, EPI_LNBWD>(g, (hipStream_t)stream);
   if (K == 576) return launch_ws<9, 2, 32>(g, EPI_LNBWD, (hipStream_t)stream);
   return launch_ws<12, 2, 32>(g, EPI_LNBWD, (hipStream_t)stream);
 }

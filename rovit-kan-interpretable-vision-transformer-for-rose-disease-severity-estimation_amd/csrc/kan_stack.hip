@@ -607,7 +607,7 @@ extern "C" int rovit_kan_stack_fwd_mfma(const float* x, const float* const* wm, 
   const int fpl = H == 4 ? 4 : 1;
   // two sample tiles per wave halve the weight traffic through L2 but leave one wave per SIMD: pays when the MFMA phase
   // dominates and the batch still gives every SIMD a wave (G = 32 at batch 65536: 696 -> 618 us; G = 5: 186 -> 210 us, not used)
-  static const int ns_env = getenv("ROVIT_KAN_MFMA_NS") ? atoi(getenv("ROVIT_KAN_MFMA_NS")) : 0;
+  const int ns_env = ROVIT_KNOB(ROVIT_KNOB_KAN_MFMA_NS, 0);
   ROVIT_CHECK_ARG(ns_env >= 0 && ns_env <= 2, ROVIT_ERR_SHAPE, "kan_stack_fwd_mfma: ROVIT_KAN_MFMA_NS must be 1 or 2 (got %d)", ns_env);
   const int ns = ns_env ? ns_env : ((H == 18 && batch >= 49152) ? 2 : 1);
   const int grid = (batch + KM_TS * ns - 1) / (KM_TS * ns);

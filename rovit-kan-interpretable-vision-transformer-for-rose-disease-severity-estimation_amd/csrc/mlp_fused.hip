@@ -48,6 +48,12 @@
 #define ROVIT_MLP_PIPE_SKEW 1
 #endif
 
+#ifdef ROVIT_DEV
+#define MLP_DBG(g, bit) ((g).dbg & (bit))
+#else
+#define MLP_DBG(g, bit) (false)    // the product kernels have no skip-work path
+#endif
+
 namespace {
 
 constexpr int D = 192, HID = 768, HC = 32, NCHUNK = HID / HC;
@@ -109,7 +115,9 @@ struct MlpArgs {
   bf16* xb;               // backward: (M,192) bf16 copy of the updated dX
   float eps;
   int M;
-  int dbg;                // developer knob (timing ablations of the lockstep kernel): bit 0 skip the row-wise epilogue, 1 skip GELU, 2 skip fc2, 3 skip fc1
+#ifdef ROVIT_DEV
+  int dbg;                // developer library only (ROVIT_KNOB_MLP_DBG, timing ablations): bit 0 skip the row-wise epilogue, 1 skip GELU, 2 skip fc2, 3 skip fc1
+#endif
 };
 
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
       for (int ks = 0; ks < 6; ++ks) {
         const bf16x8 wa = *(const bf16x8*)(sb + ks * PIECE), wb = *(const bf16x8*)(sb + (6 + ks) * PIECE);
         const bf16x8 x1 = *(const bf16x8*)(xl + ks * PIECE);
-        if (g.dbg & 8) continue;
+        if MLP_DBG(g, 8) continue;
         a1[0][0] = mfma16(wa, xf[0][ks], a1[0][0]);
         a1[1][0] = mfma16(wb, xf[0][ks], a1[1][0]);
         a1[0][1] = mfma16(wa, x1, a1[0][1]);
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float ga, gd;
-        if (g.dbg & 2) { av[r] = (bf16)pa[r]; dv[r] = av[r]; av[4 + r] = (bf16)pb[r]; dv[4 + r] = av[4 + r]; continue; }
+        if MLP_DBG(g, 2) { av[r] = (bf16)pa[r]; dv[r] = av[r]; av[4 + r] = (bf16)pb[r]; dv[4 + r] = av[4 + r]; continue; }
         gelu_and_grad((float)(bf16)pa[r], ga, gd);
         av[r] = (bf16)ga; dv[r] = (bf16)gd;
         gelu_and_grad((float)(bf16)pb[r], ga, gd);
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
 #pragma unroll
       for (int ot = 0; ot < 12; ++ot) {
         const bf16x8 w2 = *(const bf16x8*)(sb + (12 + ot) * PIECE);
-        if (g.dbg & 4) continue;
+        if MLP_DBG(g, 4) continue;
         a2[ot][0] = mfma16(w2, av0, a2[ot][0]);
         a2[ot][1] = mfma16(w2, av1, a2[ot][1]);
       }
@@ -591,7 +599,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
     } else {
       a1[0][0] = a1[0][1] = a1[1][0] = a1[1][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    if (!(g.dbg & 8))
+    if (!MLP_DBG(g, 8))
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) {
       const bf16x8 wa = *(const bf16x8*)(sb + ks * PIECE), wb = *(const bf16x8*)(sb + (6 + ks) * PIECE);
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float ga, gd;
-            if (g.dbg & 2) { ga = a1[t][i][r]; gd = ga; }
+            if MLP_DBG(g, 2) { ga = a1[t][i][r]; gd = ga; }
             else gelu_and_grad((float)(bf16)a1[t][i][r], ga, gd);      // the two-launch path's GELU sees the bf16-staged pre-activation
             av[i][4 * t + r] = (bf16)ga;
             dv[i][4 * t + r] = (bf16)gd;
@@ -635,7 +643,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
       }
     }
     // ---- second GEMM: out^T[192][32 rows] += W[:, chunk] act^T ----
-    if (!(g.dbg & 4))
+    if (!MLP_DBG(g, 4))
 #pragma unroll
     for (int ot = 0; ot < 12; ++ot) {
       const bf16x8 w2 = *(const bf16x8*)(sb + (12 + ot) * PIECE);
@@ -816,7 +824,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
   // ---- epilogue: bf16(out [+ b2]) staged in LDS (aliases the ring: every wave must have left the loop) ----
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  if (g.dbg & 1) {                                          // timing ablation: no epilogue (keep the accumulators alive)
+  if MLP_DBG(g, 1) {                                          // timing ablation: no epilogue (keep the accumulators alive)
     if (a2[0][0][0] == 12345.678f && a2[11][1][3] == 1.f) g.X[0] = a2[5][0][1];
     return;
   }
@@ -1040,39 +1048,21 @@ __global__ __launch_bounds__(256) void mlp_gelu_table_kernel(const MlpPrepArgs a
 
 }  // namespace
 
-// developer knob (A/B timing): waves per workgroup of the fused MLP forward, 8 (one 256-row workgroup per CU) or 4 (two 128-row
-// workgroups per CU); environment ROVIT_MLP_WAVES
-// (measured on MI355X, batch 256, training step: 8 waves 5.86 ms, 4 waves 5.97 ms, two-launch MLP half 5.96 ms)
-static int g_mlp_waves = [] { const char* e = getenv("ROVIT_MLP_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
-// waves 4-7 half a chunk behind waves 0-3 (see the kernel): OPT-IN (ROVIT_MLP_STAGGER=1 / rovit_set_mlp_waves(9)).  Measured with the
-// ablation knobs (tools/mlp_ablate.py, profiles/r03_mlp_ablation.json): in lockstep the launch is the SUM of its parts --
-// ring + barriers 14 us, matrix pipe 20 us, GELU 22 us, row-wise epilogue 16 us (inference variant, 71 us on that box) --
-// and the stagger does hide the GELU behind the partner's matrix segments (22 -> 10 us exposed), but the two extra barriers per
-// chunk and the LDS-resident fragments give 5 us back: 68 against 71 us on one box, 76 against 75 on another.  Not a robust
-// win, so the simpler lockstep kernel stays the default.
-static int g_mlp_stagger = [] { const char* e = getenv("ROVIT_MLP_STAGGER"); return (e && e[0] == '1') ? 1 : 0; }();
-// in-wave pipeline + GELU table (see the kernel): the DEFAULT since it was measured (MI355X, M = 50 432): 64.2 against 75.0 us per
-// training launch, 56.9 against 66.8 us per inference launch, batch-256 inference forward 1.58 against 1.69 ms; inside the training
-// step, where the forward is bound by the act / gelu' stores of two concurrent half-batch chains, 5.39 against 5.41 ms.
-// ROVIT_MLP_PIPE=0 / rovit_set_mlp_waves(8): the lockstep kernel.
-static int g_mlp_pipe = [] { const char* e = getenv("ROVIT_MLP_PIPE"); return (e && e[0] == '0') ? 0 : 1; }();
-extern "C" int rovit_set_mlp_waves(int nw) {
-  ROVIT_CHECK_ARG(nw == 4 || nw == 8 || nw == 9 || nw == 10, ROVIT_ERR_SHAPE,
-                  "set_mlp_waves: 4, 8, 9 (= 8 waves, staggered) or 10 (= 8 waves, in-wave pipeline) (got %d)", nw);
-  g_mlp_stagger = nw == 9;
-  g_mlp_pipe = nw == 10;
-  g_mlp_waves = nw >= 9 ? 8 : nw;
-  return ROVIT_OK;
+// Schedule of the fused MLP forward.  The product runs ONE: 8 waves, in-wave software pipeline (fc1 of chunk j under the GELU of chunk
+// j - 1) with the GELU looked up in an LDS table of the bf16 input patterns.  Measured against it on MI355X, M = 50 432 (developer
+// library, ROVIT_KNOB_MLP_SCHEDULE; tools/mlp_ablate.py, profiles/r03_mlp_ablation.json): 8 = 8 waves in lockstep, exact-erf GELU in the
+// loop (75.0 against 64.2 us per training launch), 9 = waves 4-7 staggered half a chunk behind waves 0-3 (68 against 71 us lockstep
+// on one box, 76 against 75 on another: the two extra barriers per chunk give back what the hidden GELU gains), 4 = two 128-row
+// workgroups of four waves per CU (each streams the whole 590 KB: step 5.97 against 5.86 ms).
+static int mlp_schedule() { return ROVIT_KNOB(ROVIT_KNOB_MLP_SCHEDULE, 10); }
+// token rows per workgroup of the 8-wave kernels: a launch lasts as long as ONE workgroup (197 workgroups of 256 rows at batch 256 run
+// side by side on 256 CUs), so while everything fits one round, 240 rows per workgroup (211 workgroups, one idle row tile each) shorten
+// it: step 4.76 -> 4.69 ms, batch-256 inference 1.30 -> 1.28 ms; from two rounds on (batch 512: 2.26 -> 2.33 ms) full workgroups win.
+static int mlp_rpw(long total_rows) {
+  const int forced = ROVIT_KNOB(ROVIT_KNOB_MLP_RPW, 0);
+  if (forced >= 16 && forced <= 256) return forced;
+  return (total_rows + 239) / 240 <= 256 ? 240 : 256;
 }
-
-static int g_mlp_dbg = 0;
-// token rows per workgroup of the 8-wave kernels (developer knob ROVIT_MLP_RPW; 256 = every row tile used)
-// 0 (default) = by size: a launch of the 8-wave kernels lasts as long as ONE workgroup (197 workgroups of 256 rows at batch 256 run side
-// by side on 256 CUs), so while everything fits one round, 240 rows per workgroup (211 workgroups, one idle row tile each) shorten it:
-// step 4.76 -> 4.69 ms, batch-256 inference 1.30 -> 1.28 ms; from two rounds on (batch 512: 2.26 -> 2.33 ms) full workgroups win.
-static int g_mlp_rpw = [] { const char* e = getenv("ROVIT_MLP_RPW"); const int v = e ? atoi(e) : 0; return (v >= 16 && v <= 256) ? v : 0; }();
-static int mlp_rpw(long total_rows) { return g_mlp_rpw ? g_mlp_rpw : ((total_rows + 239) / 240 <= 256 ? 240 : 256); }
-extern "C" int rovit_set_mlp_debug(int bits) { g_mlp_dbg = bits; return ROVIT_OK; }
 
 extern "C" size_t rovit_mlp_stream_bytes(void) { return (size_t)STREAM_ENTRIES * CH_ELEMS * sizeof(bf16) + GT_ENTRIES * sizeof(unsigned); }
 
@@ -1093,12 +1083,14 @@ static int mlp_prepare_stream_impl(const void* w1f, const void* w2, const void* 
 extern "C" int rovit_mlp_prepare_stream(const void* w1f, const void* w2, void* wstream, rovit_stream_t stream) {
   return mlp_prepare_stream_impl(w1f, w2, nullptr, wstream, stream);
 }
+#ifdef ROVIT_DEV
 // the dgrad image with the backward block tail (rovit_block_tail_bwd): w1f := W2T (768,192), w2 := W1T folded (192,768), wprojT = the
 // TRANSPOSED bf16 proj weight (192,192), row d = the weights of attention-output column d
 extern "C" int rovit_mlp_prepare_stream_tail_bwd(const void* w2T, const void* w1T, const void* wprojT, void* wstream, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(wprojT && rovit_aligned16(wprojT), ROVIT_ERR_NULL, "mlp_prepare_stream_tail_bwd: wprojT missing or misaligned");
   return mlp_prepare_stream_impl(w2T, w1T, wprojT, wstream, stream, 1);
 }
+#endif
 // ... with the block-tail image too (rovit_block_tail_fwd): wproj = the bf16 attention-output projection weight (192,192)
 // wqkv_next (may be NULL): the bf16 qkv weight (576,192) of the NEXT block with its norm1 affine folded in -- rovit_block_tail_fwd then
 // also writes that block's qkv projection
@@ -1137,18 +1129,16 @@ extern "C" int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const
                   ROVIT_ERR_ALIGN, "mlp_fused_fwd: buffers must be 16-byte aligned");
   MlpArgs g{};
   g.xin = (const bf16*)xhat2; g.wstream = (const bf16*)wstream; g.b1 = b1; g.b2 = b2; g.act = (bf16*)act; g.dact = (bf16*)dact;
-  g.X = X; g.xhat = (bf16*)xhat_out; g.rstd = rstd_out; g.eps = eps; g.M = M; g.act_rows = act_rows; g.dbg = g_mlp_dbg;
+  g.X = X; g.xhat = (bf16*)xhat_out; g.rstd = rstd_out; g.eps = eps; g.M = M; g.act_rows = act_rows;
+#ifdef ROVIT_DEV
+  g.dbg = ROVIT_KNOB(ROVIT_KNOB_MLP_DBG, 0);
+#endif
   hipStream_t st = (hipStream_t)stream;
-  const int nw = g_mlp_waves;
+  const int sched = mlp_schedule();
+  const int nw = sched == 4 ? 4 : 8;
   g.rpw = nw == 8 ? mlp_rpw(act_rows) : 32 * nw;
   const dim3 grid((M + g.rpw - 1) / g.rpw), block(64 * nw);
-#define LAUNCH_MODE(MD, NWV)                                                                                                     \
-  do {                                                                                                                           \
-    ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<0, MD, NWV>, lds_bytes(0, NWV)), ROVIT_ERR_LAUNCH,           \
-                    "mlp_fused_fwd: cannot raise the LDS limit");                                                                \
-    hipLaunchKernelGGL((mlp_fused_kernel<0, MD, NWV>), grid, block, lds_bytes(0, NWV), st, g);                                   \
-  } while (0)
-  if (nw == 8 && g_mlp_pipe) {
+  if (sched == 10) {
     g.gelu_table = g.wstream + (size_t)STREAM_ENTRIES * CH_ELEMS;
     g.wstream += (size_t)NCHUNK * CH_ELEMS;                // the skewed image
 #define LAUNCH_PIPE(MD)                                                                                                          \
@@ -1159,7 +1149,15 @@ extern "C" int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const
   } while (0)
     if (!act) LAUNCH_PIPE(0); else if (!dact) LAUNCH_PIPE(1); else LAUNCH_PIPE(2);
 #undef LAUNCH_PIPE
-  } else if (nw == 8 && g_mlp_stagger) {
+  }
+#ifdef ROVIT_DEV          // the schedules that lost (see mlp_schedule): A/B in the developer library only
+#define LAUNCH_MODE(MD, NWV)                                                                                                     \
+  do {                                                                                                                           \
+    ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<0, MD, NWV>, lds_bytes(0, NWV)), ROVIT_ERR_LAUNCH,           \
+                    "mlp_fused_fwd: cannot raise the LDS limit");                                                                \
+    hipLaunchKernelGGL((mlp_fused_kernel<0, MD, NWV>), grid, block, lds_bytes(0, NWV), st, g);                                   \
+  } while (0)
+  else if (sched == 9) {
 #define LAUNCH_STAG(MD)                                                                                                          \
   do {                                                                                                                           \
     ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<0, MD, 8, true>, lds_bytes(0, 8) + 8 * 6 * 1024), ROVIT_ERR_LAUNCH, \
@@ -1168,12 +1166,17 @@ extern "C" int rovit_mlp_fused_fwd(const void* xhat2, const void* wstream, const
   } while (0)
     if (!act) LAUNCH_STAG(0); else if (!dact) LAUNCH_STAG(1); else LAUNCH_STAG(2);
 #undef LAUNCH_STAG
-  } else if (nw == 8) {
+  } else if (sched == 8) {
     if (!act) LAUNCH_MODE(0, 8); else if (!dact) LAUNCH_MODE(1, 8); else LAUNCH_MODE(2, 8);
-  } else {
+  } else if (sched == 4) {
     if (!act) LAUNCH_MODE(0, 4); else if (!dact) LAUNCH_MODE(1, 4); else LAUNCH_MODE(2, 4);
   }
 #undef LAUNCH_MODE
+#endif
+  else {
+    rovit_set_error("mlp_fused_fwd: unknown schedule %d", sched);
+    return ROVIT_ERR_SHAPE;
+  }
   ROVIT_CHECK_LAUNCH("mlp_fused_kernel (forward)");
   return ROVIT_OK;
 }
@@ -1231,7 +1234,10 @@ extern "C" int rovit_mlp_fused_bwd(const void* dY, const void* wstream_bwd, cons
                   ROVIT_ERR_ALIGN, "mlp_fused_bwd: buffers must be 16-byte aligned");
   MlpArgs g{};
   g.xin = (const bf16*)dY; g.wstream = (const bf16*)wstream_bwd; g.act = (bf16*)dpre; g.mul = (const bf16*)dact; g.X = dX;
-  g.xhat = (bf16*)const_cast<void*>(xhat2); g.rstd = const_cast<float*>(rstd2); g.xb = (bf16*)dXb; g.M = M; g.dbg = g_mlp_dbg;
+  g.xhat = (bf16*)const_cast<void*>(xhat2); g.rstd = const_cast<float*>(rstd2); g.xb = (bf16*)dXb; g.M = M;
+#ifdef ROVIT_DEV
+  g.dbg = ROVIT_KNOB(ROVIT_KNOB_MLP_DBG, 0);
+#endif
   ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<1, 1, 8>, lds_bytes(1, 8)), ROVIT_ERR_LAUNCH,
                   "mlp_fused_bwd: cannot raise the LDS limit");
   g.rpw = mlp_rpw(M);
@@ -1240,6 +1246,7 @@ extern "C" int rovit_mlp_fused_bwd(const void* dY, const void* wstream_bwd, cons
   return ROVIT_OK;
 }
 
+#ifdef ROVIT_DEV      // round 3's backward block tail: measured slower in the step (4.87 against 4.78 ms), developer library only
 // rovit_mlp_fused_bwd with the norm2 backward in registers (fp32 dxhat2, nothing staged through bf16) and, behind it, the proj dgrad
 // dO (M,192) = dXb Wproj in the same launch (dO NULL: none).  wstream_bwd from rovit_mlp_prepare_stream_tail_bwd.
 extern "C" int rovit_block_tail_bwd(const void* dY, const void* wstream_bwd, const void* dact, void* dpre, const void* xhat2,
@@ -1252,7 +1259,10 @@ extern "C" int rovit_block_tail_bwd(const void* dY, const void* wstream_bwd, con
   MlpArgs g{};
   g.xin = (const bf16*)dY; g.act = (bf16*)dpre; g.mul = (const bf16*)dact; g.X = dX; g.dO = (bf16*)dO;
   g.wstream = (const bf16*)wstream_bwd + (size_t)(NCHUNK + PENTRIES) * CH_ELEMS;      // the backward block-tail image
-  g.xhat = (bf16*)const_cast<void*>(xhat2); g.rstd = const_cast<float*>(rstd2); g.xb = (bf16*)dXb; g.M = M; g.dbg = g_mlp_dbg;
+  g.xhat = (bf16*)const_cast<void*>(xhat2); g.rstd = const_cast<float*>(rstd2); g.xb = (bf16*)dXb; g.M = M;
+#ifdef ROVIT_DEV
+  g.dbg = ROVIT_KNOB(ROVIT_KNOB_MLP_DBG, 0);
+#endif
   ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<1, 1, 8, false, false, true>, lds_bytes(1, 8)), ROVIT_ERR_LAUNCH,
                   "block_tail_bwd: cannot raise the LDS limit");
   g.rpw = mlp_rpw(M);
@@ -1260,3 +1270,4 @@ extern "C" int rovit_block_tail_bwd(const void* dY, const void* wstream_bwd, con
   ROVIT_CHECK_LAUNCH("mlp_fused_kernel (backward block tail)");
   return ROVIT_OK;
 }
+#endif

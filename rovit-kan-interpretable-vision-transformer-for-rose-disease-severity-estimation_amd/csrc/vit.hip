@@ -13,7 +13,6 @@
 //   LayerNorm affines are folded into the following Linear (W*gamma, b + W beta) by rovit_vit_prepare, so the
 //   GEMM operand is the normalised xhat itself and the wgrad recovers dgamma/dbeta from G = dY^T xhat.
 #include <algorithm>
-#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -27,31 +26,16 @@ enum { B_N1W = 0, B_N1B, B_QKVW, B_QKVB, B_PROJW, B_PROJB, B_N2W, B_N2B, B_FC1W,
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// ROVIT_RECOMPUTE_GELU=1: do not store gelu'(pre) in the forward (77 MB per block at batch 256, 0.93 GB per step) and let
-// the backward recompute it from xhat2 (rovit_gemm_mlp_bwd).  Measured on MI355X at batch 256: forward fc1 51.1 -> 49.5 us
-// but backward 40.2 -> 64.2 us per block (the recompute makes the kernel VALU/phase-bound), so it is a MEMORY option,
-// not the default.
-inline bool recompute_gelu() {
-  static const bool on = [] { const char* e = getenv("ROVIT_RECOMPUTE_GELU"); return e && e[0] == '1'; }();
-  return on;
-}
-
-// token rows (batch x 197) from which the one-launch MLP half (mlp_fused.hip) is used; below it the two-launch kernels.
-// Measured crossover on MI355X (tools/fwd_small_batch.py, bench.py --batch n): batch 176 for the inference forward (1.52 ms
-// either way; batch 128: 1.33 fused against 1.23 ms, batch 1: 0.99 against 0.66 ms) and for the training step alike.
-int g_mlp_fused_min_rows = [] { const char* e = getenv("ROVIT_MLP_FUSED_MIN_ROWS"); return e ? atoi(e) : 34000; }();
-inline int mlp_fused_min_rows() { return g_mlp_fused_min_rows; }
-// ONE decision for the forward, the dgrad chain and the weight gradients of a training step: the one-launch kernels keep act, gelu'
-// and dpre CHUNK-MAJOR ([24][M][32], mlp_fused.hip), the two-launch kernels row-major, and the weight-gradient launch is told which
-// (RovitWgradDesc::a_blk / y_blk).  Any of the A/B knobs (ROVIT_MLP_FUSED=0, ROVIT_MLP_BWD_FUSED=0, ROVIT_RECOMPUTE_GELU=1,
-// ROVIT_WGRAD_MERGE=0) therefore selects the two-launch path for all three.  The setting must not change between a forward and
-// its backward.
-inline bool mlp_one_launch(long rows) {
-  static const bool on = [] {
-    auto off = [](const char* k) { const char* e = getenv(k); return e && e[0] == '0'; };
-    return !off("ROVIT_MLP_FUSED") && !off("ROVIT_MLP_BWD_FUSED") && !off("ROVIT_WGRAD_MERGE");
-  }();
-  return on && !recompute_gelu() && rows >= mlp_fused_min_rows();
+// Which MLP half a call runs -- an ARGUMENT of rovit_vit_forward / rovit_vit_backward (`mlp_path`), not library state: the forward, the
+// dgrad chain and the weight gradients of a training step must agree on it, because the one-launch kernels (mlp_fused.hip) keep act,
+// gelu' and dpre CHUNK-MAJOR ([24][M][32]) and the two-launch kernels row-major (RovitWgradDesc::a_blk / y_blk tells the weight-gradient
+// launch which).  ROVIT_MLP_AUTO picks by size: a fused launch has one workgroup per 240 / 256 token rows, so below 34 000 rows (batch 173)
+// the two-launch kernels, whose grids also split the output columns, fill the chip better.  Measured crossover on MI355X
+// (tools/fwd_small_batch.py, bench.py --batch n): batch 176 for the inference forward (1.52 ms either way; batch 128: 1.33 fused against
+// 1.23 ms, batch 1: 0.99 against 0.66 ms) and for the training step alike.
+constexpr long MLP_FUSED_MIN_ROWS = 34000;
+inline bool mlp_one_launch(int mlp_path, long rows) {
+  return mlp_path == ROVIT_MLP_ONE_LAUNCH || (mlp_path == ROVIT_MLP_AUTO && rows >= MLP_FUSED_MIN_ROWS);
 }
 
 struct Prep {          // byte offsets into the prepared-weight buffer
@@ -109,7 +93,7 @@ struct Plan {          // byte offsets into the workspace
     xhat2 = b; b = al(b + M * D * 2);
     rstd2 = b; b = al(b + M * 4);
     act = b; b = al(b + M * MLP * 2);
-    dact = b; if (!recompute_gelu()) b = al(b + M * MLP * 2);   // gelu'(pre): stored, or recomputed by the backward
+    dact = b; b = al(b + M * MLP * 2);          // gelu'(pre)
     blk_stride = training ? b : 0;              // inference: every block reuses the same buffers
     blk0 = o; o += training ? (size_t)depth * b : b;
     s_qkv = rovit_wgrad_splits((int)M, 3 * D, D);
@@ -173,13 +157,11 @@ SideStream* side_stream() {
     // A stream of its own PRIORITY class gets a hardware queue of its own.  Normal-priority streams share at most
     // GPU_MAX_HW_QUEUES (4) queues round-robin; with RCCL's and torch's side streams around, a normal-priority
     // stream was observed to land on the caller's queue, which serialises the two "concurrent" chains (8.7 instead
-    // of 7.1 ms/step with a process group initialised).  High and low priority measure the same within noise.
+    // of 7.1 ms/step with a process group initialised).  High and low priority measured the same within noise: high.
     int least = 0, greatest = 0;
-    const char* pe = getenv("ROVIT_SIDE_PRIORITY");        // developer knob: high (default) | low | normal
-    const bool normal = pe && pe[0] == 'n', high = !(pe && pe[0] == 'l');
-    if (normal || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) {
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) {
       if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    } else if (hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, high ? greatest : least) != hipSuccess) {
+    } else if (hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, greatest) != hipSuccess) {
       return nullptr;
     }
   }
@@ -193,27 +175,19 @@ hipEvent_t hand_over(SideStream* ss, hipStream_t from, hipStream_t to, bool reco
   if (!record_only && hipStreamWaitEvent(to, e, 0) != hipSuccess) return nullptr;
   return e;
 }
-// ROVIT_SINGLE_STREAM=1 keeps the whole backward on the caller's stream (debugging / A-B timing)
-bool two_streams_enabled() {
-  static const bool on = [] { const char* e = getenv("ROVIT_SINGLE_STREAM"); return !(e && e[0] == '1'); }();
-  return on;
-}
+// developer library only (ROVIT_KNOB_SINGLE_STREAM): everything on the caller's stream -- serial per-kernel times for the profiles
+bool two_streams_enabled() { return !ROVIT_KNOB(ROVIT_KNOB_SINGLE_STREAM, 0); }
 
-int check_common(const void* params, const void* prep, const void* ws, int batch, int depth) {
+int check_common(const void* params, const void* prep, const void* ws, int batch, int depth, int mlp_path = ROVIT_MLP_AUTO) {
   ROVIT_CHECK_ARG(params && prep && ws, ROVIT_ERR_NULL, "vit: null params/prep/workspace");
+  ROVIT_CHECK_ARG(mlp_path == ROVIT_MLP_AUTO || mlp_path == ROVIT_MLP_TWO_LAUNCH || mlp_path == ROVIT_MLP_ONE_LAUNCH, ROVIT_ERR_SHAPE,
+                  "vit: mlp_path must be ROVIT_MLP_AUTO, _TWO_LAUNCH or _ONE_LAUNCH (got %d)", mlp_path);
   ROVIT_CHECK_ARG(batch > 0 && depth > 0 && depth <= 64, ROVIT_ERR_SHAPE, "vit: bad batch %d / depth %d", batch, depth);
   ROVIT_CHECK_ARG(rovit_aligned16(prep) && rovit_aligned16(ws), ROVIT_ERR_ALIGN, "vit: prep/workspace must be 16-byte aligned");
   return ROVIT_OK;
 }
 
 }  // namespace
-
-// token rows (batch x 197) from which rovit_vit_forward / rovit_vit_backward use the one-launch MLP half; 0 = always, a huge value = never
-extern "C" int rovit_set_mlp_fused_min_rows(int rows) {
-  ROVIT_CHECK_ARG(rows >= 0, ROVIT_ERR_SHAPE, "set_mlp_fused_min_rows: rows >= 0 (got %d)", rows);
-  g_mlp_fused_min_rows = rows;
-  return ROVIT_OK;
-}
 
 extern "C" size_t rovit_vit_prep_bytes(int depth) { return Prep(depth).total; }
 extern "C" size_t rovit_vit_workspace_bytes(int batch, int depth, int training) { return Plan(batch, depth, training).total; }
@@ -264,9 +238,10 @@ extern "C" int rovit_vit_prepare(const float* const* params, void* prep, int dep
 
 namespace {
 int vit_forward_impl(const float* images, const float* const* params, const void* prep, void* workspace, float* features,
-                     void* const* attn_taps, float* const* prob_taps, int batch, int depth, int training, rovit_stream_t stream) {
+                     void* const* attn_taps, float* const* prob_taps, int batch, int depth, int training, int mlp_path,
+                     rovit_stream_t stream) {
   ROVIT_CHECK_ARG(images && features, ROVIT_ERR_NULL, "vit_forward: null images/features");
-  RUN(check_common(params, prep, workspace, batch, depth));
+  RUN(check_common(params, prep, workspace, batch, depth, mlp_path));
   const Prep P(depth);
   const Plan L(batch, depth, training);
   const char* pb = (const char*)prep;
@@ -281,17 +256,14 @@ int vit_forward_impl(const float* images, const float* const* params, const void
   // chain on two HIP streams with no synchronisation until the final norm: every kernel here is a 20-50 us
   // persistent launch with ~6 us of ramp (dispatch, weight prologue, first tile, tail), which the other half's
   // kernels now cover.  Each half asks for half of the CUs (rovit_set_cu_budget) so the two chains co-reside.
-  static const bool fwd_split = !getenv("ROVIT_FWD_SINGLE");
-  SideStream* ss = (two_streams_enabled() && fwd_split && !attn_taps && !prob_taps && batch >= 16) ? side_stream() : nullptr;
+  SideStream* ss = (two_streams_enabled() && !attn_taps && !prob_taps && batch >= 16) ? side_stream() : nullptr;
   struct Half { int b0, nb; rovit_stream_t st; };
   Half halves[2] = {{0, ss ? (batch + 1) / 2 : batch, stream}, {(batch + 1) / 2, ss ? batch / 2 : 0, ss ? (rovit_stream_t)ss->stream : stream}};
-  if (ss && getenv("ROVIT_DBG_SAME_STREAM")) halves[1].st = stream;
   const int nh = ss ? 2 : 1;
   if (ss) {
     ss->next = 0;
     if (!hand_over(ss, (hipStream_t)stream, ss->stream)) { rovit_set_error("vit_forward: event hand-over failed"); return ROVIT_ERR_LAUNCH; }
-    static const int budget = getenv("ROVIT_FWD_BUDGET") ? atoi(getenv("ROVIT_FWD_BUDGET")) : 128;
-    rovit_set_cu_budget(budget);
+    rovit_set_cu_budget(128);
   }
   struct BudgetReset { bool on; ~BudgetReset() { if (on) rovit_set_cu_budget(256); } } budget_reset{ss != nullptr};
 #define EACH_HALF for (int hh = 0; hh < nh; ++hh)
@@ -308,28 +280,20 @@ int vit_forward_impl(const float* images, const float* const* params, const void
 #define ROWS(ptr, width, esz) ((ptr) + (size_t)h.b0 * T * (width) * (esz))
     // LayerNorm1 of block 0 is a kernel of its own; every other LayerNorm of the loop is fused into the epilogue
     // of the GEMM that produces its input (proj -> norm2, fc2 -> next block's norm1).
-    // Stagger (ROVIT_FWD_STAGGER=1): the second half starts after the first half's attention of block 0, so that from then on
-    // an attention kernel (LDS/MFMA-bound) of one half runs beside a GEMM (HBM-bound) of the other instead of beside its twin.
-    static const bool stagger = getenv("ROVIT_FWD_STAGGER") && getenv("ROVIT_FWD_STAGGER")[0] == '1';
-    const bool stag0 = stagger && ss && i == 0;
-    for (int pass = 0; pass < (stag0 ? 2 : 1); ++pass) {
-      const int h_lo = stag0 ? pass : 0, h_hi = stag0 ? pass + 1 : nh;
-      if (stag0 && pass == 1 && !hand_over(ss, (hipStream_t)stream, ss->stream)) { rovit_set_error("vit_forward: event hand-over failed"); return ROVIT_ERR_LAUNCH; }
-      if (i == 0) for (int hh = h_lo; hh < h_hi; ++hh) {
-        const Half& h = halves[hh];
-        RUN(rovit_layernorm_fwd(X + (size_t)h.b0 * T * D, ROWS(s + L.xhat1, D, 2), (float*)ROWS(s + L.rstd1, 1, 4), h.nb * T, D, eps, h.st));
-      }
-      if (!qkv_done) for (int hh = h_lo; hh < h_hi; ++hh) {
-        const Half& h = halves[hh];
-        RUN(rovit_gemm_nt(ROWS(s + L.xhat1, D, 2), D, q + P.wqkv, D, h.nb * T, 3 * D, D, (const float*)(q + P.bqkv), EPI_BF16,
-                          ROWS(s + L.qkv, 3 * D, 2), 3 * D, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, h.st));
-      }
-      qkv_done = false;
-      for (int hh = h_lo; hh < h_hi; ++hh) {
-        const Half& h = halves[hh];
-        RUN(rovit_attention_fwd(ROWS(s + L.qkv, 3 * D, 2), ROWS(s + L.o, D, 2), (float*)(s + L.lse) + (size_t)h.b0 * H * T, h.nb, T, H, D / H,
-                                0.125f, h.st));
-      }
+    if (i == 0) EACH_HALF {
+      const Half& h = halves[hh];
+      RUN(rovit_layernorm_fwd(X + (size_t)h.b0 * T * D, ROWS(s + L.xhat1, D, 2), (float*)ROWS(s + L.rstd1, 1, 4), h.nb * T, D, eps, h.st));
+    }
+    if (!qkv_done) EACH_HALF {
+      const Half& h = halves[hh];
+      RUN(rovit_gemm_nt(ROWS(s + L.xhat1, D, 2), D, q + P.wqkv, D, h.nb * T, 3 * D, D, (const float*)(q + P.bqkv), EPI_BF16,
+                        ROWS(s + L.qkv, 3 * D, 2), 3 * D, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, h.st));
+    }
+    qkv_done = false;
+    EACH_HALF {
+      const Half& h = halves[hh];
+      RUN(rovit_attention_fwd(ROWS(s + L.qkv, 3 * D, 2), ROWS(s + L.o, D, 2), (float*)(s + L.lse) + (size_t)h.b0 * H * T, h.nb, T, H, D / H,
+                              0.125f, h.st));
     }
     // explainability tap: the attention module's output (proj(attention) + bias, before the residual add) for
     // every token of block i -- what a forward hook on `blocks[i].attn` sees (reference models/backbone.py:37-62)
@@ -340,17 +304,14 @@ int vit_forward_impl(const float* images, const float* const* params, const void
     // (explainability/attention_maps.py:18-105)
     if (prob_taps && prob_taps[i]) RUN(rovit_attention_probs(s + L.qkv, prob_taps[i], batch, T, H, D / H, 0.125f, stream));
     // Everything behind the attention in ONE launch ("block tail", mlp_fused.hip: proj + residual + norm2 + MLP + residual + next
-    // norm1; the residual stream stays in registers between the halves).  ROVIT_BLOCK_TAIL=0: proj + norm2 as their own launch.
-    static const bool block_tail = !(getenv("ROVIT_BLOCK_TAIL") && getenv("ROVIT_BLOCK_TAIL")[0] == '0');
-    if (block_tail && !cls_only && mlp_one_launch((long)batch * T)) {
+    // norm1 + the NEXT block's qkv projection; the residual stream stays in registers between the halves).
+    if (!cls_only && mlp_one_launch(mlp_path, (long)batch * T)) {
       char* sn = ws + L.blk0 + (size_t)(i + 1) * L.blk_stride;            // next block's saved-activation area
-      static const bool tail_qkv_env = !(getenv("ROVIT_BLOCK_TAIL_QKV") && getenv("ROVIT_BLOCK_TAIL_QKV")[0] == '0');
-      const bool tail_qkv = tail_qkv_env;
+      const bool tail_qkv = true;
       qkv_done = tail_qkv;                                                // block i + 1 finds its qkv projection written
       EACH_HALF {
         const Half& h = halves[hh];
         float* Xh = X + (size_t)h.b0 * T * D;
-        // ... and the NEXT block's qkv projection behind its norm1 (ROVIT_BLOCK_TAIL_QKV=0: that stays a launch of the next block)
         RUN(rovit_block_tail_fwd(ROWS(s + L.o, D, 2), q + P.wmlp, bp[B_PROJB], (const float*)(q + P.bfc1), bp[B_FC2B], Xh,
                                  training ? ROWS(s + L.xhat2, D, 2) : nullptr, training ? (float*)ROWS(s + L.rstd2, 1, 4) : nullptr,
                                  training ? ROWS(s + L.act, 32, 2) : nullptr, training ? ROWS(s + L.dact, 32, 2) : nullptr,
@@ -372,26 +333,11 @@ int vit_forward_impl(const float* images, const float* const* params, const void
                                 (float*)ROWS(s + L.rstd2, 1, 4), eps, h.st));
       }
     }
-    // MLP half: one launch (fc1 + GELU + fc2 + residual + next LayerNorm, mlp_fused.hip); `act` is never re-read, and an
-    // inference call keeps neither act nor gelu'.  ROVIT_MLP_FUSED=0: the two-launch path (A/B timing).
-    // A fused launch has one workgroup per 256 rows: below ROVIT_MLP_FUSED_MIN_ROWS rows (small batches) it leaves most of the
-    // chip idle and the two-launch path, whose grids also split the output columns, is faster.
-    if (!cls_only && mlp_one_launch((long)batch * T)) {
-      char* sn = ws + L.blk0 + (size_t)(i + 1) * L.blk_stride;            // next block's saved-activation area
-      EACH_HALF {
-        const Half& h = halves[hh];
-        float* Xh = X + (size_t)h.b0 * T * D;
-        // act / gelu' chunk-major over the WHOLE batch: this half's rows start 64 bytes x first row into every chunk
-        RUN(rovit_mlp_fused_fwd(ROWS(s + L.xhat2, D, 2), q + P.wmlp, (const float*)(q + P.bfc1), bp[B_FC2B],
-                                training ? ROWS(s + L.act, 32, 2) : nullptr, training ? ROWS(s + L.dact, 32, 2) : nullptr, Xh,
-                                ROWS(sn + L.xhat1, D, 2), (float*)ROWS(sn + L.rstd1, 1, 4), eps, h.nb * T, batch * T, h.st));
-      }
-      continue;
-    }
+    // two-launch MLP half (small batches, and the CLS rows of the last block): fc1 + GELU, then fc2 + residual + next LayerNorm
     EACH_HALF {
       const Half& h = halves[hh];
       RUN(rovit_gemm_nt(ROWS(s + L.xhat2, D, 2), D * rs, q + P.wfc1, D, cls_only ? h.nb : h.nb * T, MLP, D, (const float*)(q + P.bfc1),
-                        EPI_GELU, ROWS(s + L.act, MLP, 2), MLP * rs, (training && !recompute_gelu()) ? ROWS(s + L.dact, MLP, 2) : nullptr, nullptr, 0, nullptr, 0,
+                        EPI_GELU, ROWS(s + L.act, MLP, 2), MLP * rs, training ? ROWS(s + L.dact, MLP, 2) : nullptr, nullptr, 0, nullptr, 0,
                         nullptr, 0, h.st));
     }
     EACH_HALF {
@@ -418,8 +364,8 @@ int vit_forward_impl(const float* images, const float* const* params, const void
 
 // images fp32 NCHW (B,3,224,224) -> features fp32 (B,192)
 extern "C" int rovit_vit_forward(const float* images, const float* const* params, const void* prep, void* workspace,
-                                 float* features, int batch, int depth, int training, rovit_stream_t stream) {
-  return vit_forward_impl(images, params, prep, workspace, features, nullptr, nullptr, batch, depth, training, stream);
+                                 float* features, int batch, int depth, int training, int mlp_path, rovit_stream_t stream) {
+  return vit_forward_impl(images, params, prep, workspace, features, nullptr, nullptr, batch, depth, training, mlp_path, stream);
 }
 
 // Same forward (inference workspace), additionally writing each block's attention-module output into
@@ -429,7 +375,7 @@ extern "C" int rovit_vit_forward_taps(const float* images, const float* const* p
                                       float* features, void* const* attn_taps, float* const* prob_taps, int batch, int depth,
                                       rovit_stream_t stream) {
   ROVIT_CHECK_ARG(attn_taps || prob_taps, ROVIT_ERR_NULL, "vit_forward_taps: no tap array given");
-  return vit_forward_impl(images, params, prep, workspace, features, attn_taps, prob_taps, batch, depth, 0, stream);
+  return vit_forward_impl(images, params, prep, workspace, features, attn_taps, prob_taps, batch, depth, 0, ROVIT_MLP_AUTO, stream);
 }
 
 // Backward over blocks first_block, first_block-1, ..., last_block (inclusive).  first_block == depth-1 also
@@ -438,9 +384,9 @@ extern "C" int rovit_vit_forward_taps(const float* images, const float* const* p
 // grads[] mirrors params[]; every entry of the processed range is overwritten.
 namespace {
 int vit_backward_impl(const float* images, const float* d_features, const float* const* params, const void* prep, void* workspace,
-                      float* const* grads, int batch, int depth, int first_block, int last_block, rovit_stream_t stream,
+                      float* const* grads, int batch, int depth, int first_block, int last_block, int mlp_path, rovit_stream_t stream,
                       bool defer_join, hipStream_t notify) {
-  RUN(check_common(params, prep, workspace, batch, depth));
+  RUN(check_common(params, prep, workspace, batch, depth, mlp_path));
   ROVIT_CHECK_ARG(grads, ROVIT_ERR_NULL, "vit_backward: null grads");
   ROVIT_CHECK_ARG(first_block < depth && last_block >= 0 && first_block >= last_block, ROVIT_ERR_SHAPE,
                   "vit_backward: bad block range [%d..%d] for depth %d", first_block, last_block, depth);
@@ -449,6 +395,7 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
   const char* pb = (const char*)prep;
   char* ws = (char*)workspace;
   const int M = (int)L.M;
+  const bool one_launch = mlp_one_launch(mlp_path, M);       // the SAME decision the forward took (same argument, same row count)
   float* dX = (float*)(ws + L.dX);
   // bf16 copy of the residual-stream gradient ENTERING block i lives in x0[i % 3] (x0v(-1) feeds the patch embedding)
   auto x0v = [&](int i) { return ws + L.x0[(i + 3) % 3]; };
@@ -458,21 +405,19 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
                            x0v(depth - 1), grads[P_NORM_W], grads[P_NORM_B], batch, T, stream));
   }
   // Two-stream schedule (see SideStream above).  Per block i (p = i & 1), stream A runs the dgrad chain
-  //   A1 fc2 dgrad * gelu' (stored, or recomputed from xhat2) : x0[i%3] -> dpre[p]        A2 fc1 dgrad + norm2 bwd : dpre[p] -> dX, x1[p]
+  //   A1 + A2 MLP half (fc2 dgrad * gelu' -> dpre[p]; fc1 dgrad + norm2 bwd -> dX, x1[p]): one launch from batch 173, else two
   //   A3 proj dgrad : x1[p] -> dO                       A4 attention bwd : dO -> dqkv[p]
   //   A5 qkv dgrad + norm1 bwd : dqkv[p] -> dX, x0[(i-1)%3]
-  // and stream B the weight gradients  B1 fc2 (x0[i%3], act)  B2 fc1 (dpre[p], xhat2)  B3 proj (x1[p], o)
-  //   B4 qkv (dqkv[p], xhat1)  B5 slab reduction -> grads.
+  // and stream B the weight gradients: ONE launch per block carries fc2 (x0[i%3], act), fc1 (dpre[p], xhat2), proj (x1[p], o) of block i
+  // together with the qkv gradient (dqkv, xhat1) of the previous block (`pending`, whose dqkv became final with its A5) -- 12 output
+  // tiles (192 x 192) per M-split, so 16 splits fill the chip (gemm.hip WgradProb) -- and ONE reduce launch finishes those four.
   // Events cost ~6 us of idle time on the stream that records or waits, so A does ONE record per block (E_i, after
-  // A2) and ONE wait (for B5 of block i+2, long finished): B issues [B4 B5](i+1) [B1 B2 B3](i) behind E_i.  The
-  // rotating buffers make that safe: a buffer written by A in block i was last read by B in block i+2 (x1, dpre,
-  // dqkv: parity pairs) or i+3 (x0: three buffers, A5 of block i overwrites what B1 of block i+2 read).
+  // A2) and ONE wait (for the reduce of block i+2, long finished).  The rotating buffers make that safe: a buffer written by A in
+  // block i was last read by B in block i+2 (x1, dpre, dqkv: parity pairs) or i+3 (x0: three buffers, A5 of block i overwrites what
+  // the fc2 weight gradient of block i+2 read).
   hipStream_t sA = (hipStream_t)stream;
   SideStream* ss = two_streams_enabled() ? side_stream() : nullptr;
   hipStream_t sB = ss ? ss->stream : sA;
-  static const int bwd_budget = getenv("ROVIT_BWD_BUDGET") ? atoi(getenv("ROVIT_BWD_BUDGET")) : 256;   // developer knob
-  if (ss && bwd_budget != 256) rovit_set_cu_budget(bwd_budget);
-  struct BudgetReset { bool on; ~BudgetReset() { if (on) rovit_set_cu_budget(256); } } budget_reset{ss && bwd_budget != 256};
   static hipEvent_t no_events[64];
   if (ss && !(ss->carry && first_block != depth - 1)) {      // a new backward pass, or the previous range was joined
     ss->next = 0;
@@ -480,48 +425,25 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
   }
   if (ss) ss->carry = false;
   hipEvent_t* ev_bdone = ss ? ss->ev_bdone : no_events;
-  int pending = -1;                                   // block whose B4/B5 have not been issued yet
+  int pending = -1;                                   // block whose qkv weight gradient has not been issued yet
 #define EVFAIL(what) do { rovit_set_error("vit_backward: " what " failed"); return ROVIT_ERR_LAUNCH; } while (0)
-  auto reduce_block = [&](int i, bool cls_only, rovit_stream_t st, int n = 4) -> int {      // n = 3: without the qkv weight
-    const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
-    float* const* bg = grads + P_BLOCK0 + B_COUNT * i;
-    const int s_fc2 = cls_only ? L.s_fc2c : L.s_fc2, s_fc1 = cls_only ? L.s_fc1c : L.s_fc1, s_proj = cls_only ? L.s_projc : L.s_proj;
-    const RovitReduceDesc rd[4] = {
-        {(const float*)(ws + L.slab_fc2), s_fc2, D, MLP, nullptr, nullptr, nullptr, bg[B_FC2W], bg[B_FC2B], nullptr, nullptr, nullptr},
-        {(const float*)(ws + L.slab_fc1), s_fc1, MLP, D, bp[B_N2W], bp[B_N2B], bp[B_FC1W], bg[B_FC1W], bg[B_FC1B], bg[B_N2W], bg[B_N2B],
-         (float*)(ws + L.gscr)},
-        {(const float*)(ws + L.slab_proj), s_proj, D, D, nullptr, nullptr, nullptr, bg[B_PROJW], bg[B_PROJB], nullptr, nullptr, nullptr},
-        {(const float*)(ws + L.slab_qkv), L.s_qkv, 3 * D, D, bp[B_N1W], bp[B_N1B], bp[B_QKVW], bg[B_QKVW], bg[B_QKVB], bg[B_N1W], bg[B_N1B],
-         (float*)(ws + L.gscr2)}};
-    return rovit_wgrad_reduce_batch(rd, n, st);
-  };
-  // Weight gradients of the two-stream schedule: ONE launch per block carries the qkv gradient of the previous block
-  // (`pending`, whose dqkv became final with its A5) together with fc2 / fc1 / proj of block i -- 12 output tiles (192 x 192) per
-  // M-split, so S_MERGE splits fill the chip (see gemm.hip WgradProb) -- and ONE reduce launch finishes those four.
-  static const int s_merge_env = getenv("ROVIT_WGRAD_MERGE_SPLITS") ? atoi(getenv("ROVIT_WGRAD_MERGE_SPLITS")) : 16;   // x 12 tiles of 192 x 192 = 192 workgroups
-  static const bool merge_env = !(getenv("ROVIT_WGRAD_MERGE") && getenv("ROVIT_WGRAD_MERGE")[0] == '0');
   // never more splits than the slab buffers were sized for (small batches have few 64-row steps)
-  const int S_MERGE = std::min(std::min(s_merge_env, L.s_fc1), std::min(std::min(L.s_fc2, L.s_qkv), L.s_proj));
-  const bool merge = merge_env && S_MERGE >= 1;
+  const int S_MERGE = std::min(std::min(ROVIT_KNOB(ROVIT_KNOB_WGRAD_SPLITS, 16), L.s_fc1), std::min(std::min(L.s_fc2, L.s_qkv), L.s_proj));
+  ROVIT_CHECK_ARG(S_MERGE >= 1, ROVIT_ERR_SHAPE, "vit_backward: no weight-gradient split fits batch %d", batch);
   auto qkv_reduce_desc = [&](int i, int splits) -> RovitReduceDesc {
     const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
     float* const* bg = grads + P_BLOCK0 + B_COUNT * i;
     return {(const float*)(ws + L.slab_qkv), splits, 3 * D, D, bp[B_N1W], bp[B_N1B], bp[B_QKVW], bg[B_QKVW], bg[B_QKVB], bg[B_N1W],
             bg[B_N1B], (float*)(ws + L.gscr2)};
   };
-  auto issue_b45 = [&](int i) -> int {                 // B4 + B5 of block i (stream B already waits for A5 of block i)
+  // the qkv weight gradient of block i as a launch of its own (flush at the end of a block range).  Same kernel, tile and split count as
+  // inside a merged launch, so a backward cut into block ranges (data-parallel buckets) stays bit-identical to an uncut one.
+  auto issue_qkv = [&](int i) -> int {
     char* s = ws + L.blk0 + (size_t)i * L.blk_stride;
-    if (merge) {
-      // fc2 / fc1 / proj of block i were reduced with their own launch.  Same kernel, tile and split count as inside a
-      // merged launch, so a backward cut into block ranges (data-parallel buckets) stays bit-identical to an uncut one.
-      const RovitWgradDesc wd = {ws + L.dqkv[i & 1], 3 * D, s + L.xhat1, D, 3 * D, D, (float*)(ws + L.slab_qkv)};
-      RUN(rovit_wgrad_batch(&wd, 1, M, S_MERGE, sB));
-      const RovitReduceDesc rd = qkv_reduce_desc(i, S_MERGE);
-      RUN(rovit_wgrad_reduce_batch(&rd, 1, sB));
-    } else {
-      RUN(rovit_wgrad(ws + L.dqkv[i & 1], 3 * D, s + L.xhat1, D, M, 3 * D, D, L.s_qkv, 0, (float*)(ws + L.slab_qkv), sB));
-      RUN(reduce_block(i, false, sB));
-    }
+    const RovitWgradDesc wd = {ws + L.dqkv[i & 1], 3 * D, s + L.xhat1, D, 3 * D, D, (float*)(ws + L.slab_qkv)};
+    RUN(rovit_wgrad_batch(&wd, 1, M, S_MERGE, sB));
+    const RovitReduceDesc rd = qkv_reduce_desc(i, S_MERGE);
+    RUN(rovit_wgrad_reduce_batch(&rd, 1, sB));
     if (ss && !(ev_bdone[i] = hand_over(ss, sB, nullptr, true))) EVFAIL("event record");
     return ROVIT_OK;
   };
@@ -533,7 +455,7 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
     RovitWgradDesc wd[4];
     RovitReduceDesc rd[4];
     int n = 0;
-    const int blk = mlp_one_launch(M) ? 1 : 0;          // act and dpre chunk-major (written by the one-launch MLP kernels)
+    const int blk = one_launch ? 1 : 0;                 // act and dpre chunk-major (written by the one-launch MLP kernels)
     wd[n] = {xin, D, s + L.act, MLP, D, MLP, (float*)(ws + L.slab_fc2), blk, 0};
     rd[n++] = {(const float*)(ws + L.slab_fc2), S_MERGE, D, MLP, nullptr, nullptr, nullptr, bg[B_FC2W], bg[B_FC2B], nullptr, nullptr, nullptr};
     wd[n] = {dp, MLP, s + L.xhat2, D, MLP, D, (float*)(ws + L.slab_fc1), 0, blk};
@@ -558,77 +480,45 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
     char* xout = x0v(i - 1);
     // the last block's post-attention half only ever sees gradient on the B CLS rows (see rovit_vit_forward)
     if (i == depth - 1) {
-      // small and serial: everything on stream A; the attention-half gradient is updated in place in xin (CLS rows)
+      // small and serial on stream A (row step T: the CLS rows of the dense buffers).  Its three CLS-row weight gradients (256 rows
+      // each: 18 us apiece as separate launches, plus their reduce) run as ONE merged launch on the weight-gradient stream: for that the
+      // norm2 backward writes the bf16 gradient to the mid-block buffer instead of updating xin in place (fc2's weight gradient reads
+      // xin as it came in, proj's the updated rows).
       const int Mr = batch, rs = T;
       char* dp = ws + L.dpre[i & 1];
       char* dq = ws + L.dqkv[i & 1];
-      // Its three CLS-row weight gradients (256 rows each: 18 us apiece as separate launches, plus their reduce) run as ONE merged
-      // launch on the weight-gradient stream: for that the norm2 backward writes the bf16 gradient to the mid-block buffer instead of
-      // updating xin in place (fc2's weight gradient reads xin as it came in, proj's the updated rows).
-      static const bool cls_inline = getenv("ROVIT_LAST_CLS_INLINE") && getenv("ROVIT_LAST_CLS_INLINE")[0] == '1';      // measured: 4.63 -> 4.59 ms merged
-      if (merge && !cls_inline) {
-        char* xmc = ws + L.x1[i & 1];
-        if (recompute_gelu())
-          RUN(rovit_gemm_mlp_bwd(xin, D * rs, s + L.xhat2, D * rs, q + P.wfc2T, q + P.wfc1, (const float*)(q + P.bfc1), Mr, dp, MLP * rs, stream));
-        else
-          RUN(rovit_gemm_nt(xin, D * rs, q + P.wfc2T, D, Mr, MLP, D, nullptr, EPI_MUL, dp, MLP * rs, nullptr, nullptr, 0, s + L.dact,
-                            MLP * rs, nullptr, 0, stream));
-        RUN(rovit_gemm_nt(dp, MLP * rs, q + P.wfc1T, MLP, Mr, D, MLP, nullptr, EPI_BF16, ws + L.dxhat, D * rs, nullptr, nullptr, 0, nullptr, 0,
-                          nullptr, 0, stream));
-        RUN(rovit_layernorm_bwd_rows(ws + L.dxhat, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmc, batch, T, stream));
-        ROVIT_CHECK_ARG(hipMemsetAsync(ws + L.dO, 0, (size_t)M * D * sizeof(bf16), sA) == hipSuccess, ROVIT_ERR_LAUNCH,
-                        "vit_backward: memset failed");
-        RUN(rovit_gemm_nt(xmc, D * rs, q + P.wprojT, D, Mr, D, D, nullptr, EPI_BF16, ws + L.dO, D * rs, nullptr, nullptr, 0, nullptr, 0, nullptr,
-                          0, stream));
-        if (ss && !hand_over(ss, sA, sB)) EVFAIL("event hand-over");
-        {
-          const float* const* bpp = params + P_BLOCK0 + B_COUNT * i;
-          float* const* bg = grads + P_BLOCK0 + B_COUNT * i;
-          const int sc = std::min(std::min(4, L.s_fc2c), std::min(L.s_fc1c, L.s_projc));
-          const RovitWgradDesc wd[3] = {{xin, D * rs, s + L.act, MLP * rs, D, MLP, (float*)(ws + L.slab_fc2)},
-                                        {dp, MLP * rs, s + L.xhat2, D * rs, MLP, D, (float*)(ws + L.slab_fc1)},
-                                        {xmc, D * rs, s + L.o, D * rs, D, D, (float*)(ws + L.slab_proj)}};
-          RUN(rovit_wgrad_batch(wd, 3, Mr, sc, sB));
-          const RovitReduceDesc rd[3] = {
-              {(const float*)(ws + L.slab_fc2), sc, D, MLP, nullptr, nullptr, nullptr, bg[B_FC2W], bg[B_FC2B], nullptr, nullptr, nullptr},
-              {(const float*)(ws + L.slab_fc1), sc, MLP, D, bpp[B_N2W], bpp[B_N2B], bpp[B_FC1W], bg[B_FC1W], bg[B_FC1B], bg[B_N2W], bg[B_N2B],
-               (float*)(ws + L.gscr)},
-              {(const float*)(ws + L.slab_proj), sc, D, D, nullptr, nullptr, nullptr, bg[B_PROJW], bg[B_PROJB], nullptr, nullptr, nullptr}};
-          RUN(rovit_wgrad_reduce_batch(rd, 3, sB));
-        }
-        RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, dq, batch, T, H, D / H, 0.125f, stream));
-        RUN(rovit_gemm_ln_bwd(dq, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), dX, xout, stream));
-        pending = i;
-        continue;
-      }
-      if (recompute_gelu())
-        RUN(rovit_gemm_mlp_bwd(xin, D * rs, s + L.xhat2, D * rs, q + P.wfc2T, q + P.wfc1, (const float*)(q + P.bfc1), Mr, dp, MLP * rs, stream));
-      else
-        RUN(rovit_gemm_nt(xin, D * rs, q + P.wfc2T, D, Mr, MLP, D, nullptr, EPI_MUL, dp, MLP * rs, nullptr, nullptr, 0, s + L.dact,
-                          MLP * rs, nullptr, 0, stream));
-      RUN(rovit_wgrad(xin, D * rs, s + L.act, MLP * rs, Mr, D, MLP, L.s_fc2c, 0, (float*)(ws + L.slab_fc2), stream));
+      char* xmc = ws + L.x1[i & 1];
+      RUN(rovit_gemm_nt(xin, D * rs, q + P.wfc2T, D, Mr, MLP, D, nullptr, EPI_MUL, dp, MLP * rs, nullptr, nullptr, 0, s + L.dact,
+                        MLP * rs, nullptr, 0, stream));
       RUN(rovit_gemm_nt(dp, MLP * rs, q + P.wfc1T, MLP, Mr, D, MLP, nullptr, EPI_BF16, ws + L.dxhat, D * rs, nullptr, nullptr, 0, nullptr, 0,
                         nullptr, 0, stream));
-      RUN(rovit_wgrad(dp, MLP * rs, s + L.xhat2, D * rs, Mr, MLP, D, L.s_fc1c, 0, (float*)(ws + L.slab_fc1), stream));
-      RUN(rovit_layernorm_bwd_rows(ws + L.dxhat, s + L.xhat2, (const float*)(s + L.rstd2), dX, xin, batch, T, stream));
-      // attention backward reads dO for every query: rows other than CLS carry no gradient
+      RUN(rovit_layernorm_bwd_rows(ws + L.dxhat, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmc, batch, T, stream));
+      // attention backward reads dO for every query: rows other than CLS carry no gradient (the proj dgrad below writes the CLS rows)
       ROVIT_CHECK_ARG(hipMemsetAsync(ws + L.dO, 0, (size_t)M * D * sizeof(bf16), sA) == hipSuccess, ROVIT_ERR_LAUNCH,
                       "vit_backward: memset failed");
-      RUN(rovit_gemm_nt(xin, D * rs, q + P.wprojT, D, Mr, D, D, nullptr, EPI_BF16, ws + L.dO, D * rs, nullptr, nullptr, 0, nullptr, 0, nullptr,
+      RUN(rovit_gemm_nt(xmc, D * rs, q + P.wprojT, D, Mr, D, D, nullptr, EPI_BF16, ws + L.dO, D * rs, nullptr, nullptr, 0, nullptr, 0, nullptr,
                         0, stream));
-      RUN(rovit_wgrad(xin, D * rs, s + L.o, D * rs, Mr, D, D, L.s_projc, 0, (float*)(ws + L.slab_proj), stream));
+      if (ss && !hand_over(ss, sA, sB)) EVFAIL("event hand-over");
+      {
+        const float* const* bpp = params + P_BLOCK0 + B_COUNT * i;
+        float* const* bg = grads + P_BLOCK0 + B_COUNT * i;
+        const int sc = std::min(std::min(4, L.s_fc2c), std::min(L.s_fc1c, L.s_projc));
+        const RovitWgradDesc wd[3] = {{xin, D * rs, s + L.act, MLP * rs, D, MLP, (float*)(ws + L.slab_fc2)},
+                                      {dp, MLP * rs, s + L.xhat2, D * rs, MLP, D, (float*)(ws + L.slab_fc1)},
+                                      {xmc, D * rs, s + L.o, D * rs, D, D, (float*)(ws + L.slab_proj)}};
+        RUN(rovit_wgrad_batch(wd, 3, Mr, sc, sB));
+        const RovitReduceDesc rd[3] = {
+            {(const float*)(ws + L.slab_fc2), sc, D, MLP, nullptr, nullptr, nullptr, bg[B_FC2W], bg[B_FC2B], nullptr, nullptr, nullptr},
+            {(const float*)(ws + L.slab_fc1), sc, MLP, D, bpp[B_N2W], bpp[B_N2B], bpp[B_FC1W], bg[B_FC1W], bg[B_FC1B], bg[B_N2W], bg[B_N2B],
+             (float*)(ws + L.gscr)},
+            {(const float*)(ws + L.slab_proj), sc, D, D, nullptr, nullptr, nullptr, bg[B_PROJW], bg[B_PROJB], nullptr, nullptr, nullptr}};
+        RUN(rovit_wgrad_reduce_batch(rd, 3, sB));
+      }
       RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, dq, batch, T, H, D / H, 0.125f, stream));
       RUN(rovit_gemm_ln_bwd(dq, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), dX, xout, stream));
       // the (full-size) qkv weight gradient of this block goes the way of every other block's: as `pending`, into the next block's
       // merged launch on the weight-gradient stream (or the flush behind the loop) instead of 50 us of serial work here
-      static const bool defer_last_qkv = !(getenv("ROVIT_LAST_QKV_INLINE") && getenv("ROVIT_LAST_QKV_INLINE")[0] == '1');
-      if (defer_last_qkv) {
-        RUN(reduce_block(i, true, stream, 3));
-        pending = i;
-      } else {
-        RUN(rovit_wgrad(dq, 3 * D, s + L.xhat1, D, M, 3 * D, D, L.s_qkv, 0, (float*)(ws + L.slab_qkv), stream));
-        RUN(reduce_block(i, true, stream));
-      }
+      pending = i;
       continue;
     }
     const int p = i & 1;
@@ -636,40 +526,21 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
     char* dq = ws + L.dqkv[p];
     char* xmid = ws + L.x1[p];
     if (ss && i + 2 < depth && ev_bdone[i + 2] && hipStreamWaitEvent(sA, ev_bdone[i + 2], 0) != hipSuccess) EVFAIL("event wait");
-    // A1 + A2 in one launch (mlp_fused.hip): fc2 dgrad x gelu' -> dpre (kept for B2), fc1 dgrad + norm2 backward without
-    // re-reading dpre.  ROVIT_MLP_BWD_FUSED=0: the two launches (A/B timing); the gelu'-recompute memory mode keeps them too.
-    // The backward's counterpart of the block tail (rovit_block_tail_bwd: norm2 backward in registers on the fp32 dxhat2 -- 3 000 x
-    // closer to the fp32 reference than the bf16-staged row pass -- and the proj dgrad A3 behind it in the same launch) is OPT-IN:
-    // measured in the step it is SLOWER, 4.87 against 4.78 ms (ROVIT_BLOCK_TAIL_BWD=1; =2, register epilogue only with A3 as its own
-    // launch: 4.87) -- even with dX entering at the top of the launch (the norm2 backward is linear in dxhat2: the accumulators start as
-    // dX / rstd2); what stays behind the loop are the xhat2 loads, the shuffles and 16-byte-per-lane stores that split every 128-byte line
-    // over two instructions, where the LDS-staged pass writes whole rows.
-    static const int tail_bwd = getenv("ROVIT_BLOCK_TAIL_BWD") ? atoi(getenv("ROVIT_BLOCK_TAIL_BWD")) : 0;
-    const bool a3_fused = tail_bwd == 1 && mlp_one_launch(M);
-    if (tail_bwd && mlp_one_launch(M)) {
-      RUN(rovit_block_tail_bwd(xin, q + P.wmlpb, s + L.dact, dp, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmid, a3_fused ? ws + L.dO : nullptr, M, sA));
-    } else if (mlp_one_launch(M)) {
+    // A1 + A2 in one launch (mlp_fused.hip): fc2 dgrad x gelu' -> dpre (kept for the fc1 weight gradient), fc1 dgrad + norm2 backward
+    // without re-reading dpre; two launches below the batch threshold.  (Round 3 also built the backward's counterpart of the block tail
+    // -- norm2 backward in registers and the proj dgrad in the same launch -- and measured it SLOWER in the step, 4.87 against 4.78 ms:
+    // tools/attic)
+    if (one_launch) {
       RUN(rovit_mlp_fused_bwd(xin, q + P.wmlpb, s + L.dact, dp, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmid, M, sA));
     } else {
-      if (recompute_gelu())                                                                                            // A1
-        RUN(rovit_gemm_mlp_bwd(xin, D, s + L.xhat2, D, q + P.wfc2T, q + P.wfc1, (const float*)(q + P.bfc1), M, dp, MLP, sA));
-      else
-        RUN(rovit_gemm_nt(xin, D, q + P.wfc2T, D, M, MLP, D, nullptr, EPI_MUL, dp, MLP, nullptr, nullptr, 0, s + L.dact, MLP, nullptr, 0, sA));
+      RUN(rovit_gemm_nt(xin, D, q + P.wfc2T, D, M, MLP, D, nullptr, EPI_MUL, dp, MLP, nullptr, nullptr, 0, s + L.dact, MLP, nullptr, 0, sA));   // A1
       // fc1 dgrad fused with the backward of norm2 (updates dX, writes its bf16 copy)
       RUN(rovit_gemm_ln_bwd(dp, MLP, q + P.wfc1T, MLP, M, MLP, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmid, sA));            // A2
     }
     if (ss && !hand_over(ss, sA, sB)) EVFAIL("event hand-over");                                                   // E_i
-    if (merge) {
-      RUN(issue_merged(i, pending, xin, dp, xmid));                                                                // B4(prev) B1 B2 B3, B5
-    } else {
-      if (pending >= 0) RUN(issue_b45(pending));
-      RUN(rovit_wgrad(xin, D, s + L.act, MLP, M, D, MLP, L.s_fc2, 0, (float*)(ws + L.slab_fc2), sB));              // B1
-      RUN(rovit_wgrad(dp, MLP, s + L.xhat2, D, M, MLP, D, L.s_fc1, 0, (float*)(ws + L.slab_fc1), sB));             // B2
-      RUN(rovit_wgrad(xmid, D, s + L.o, D, M, D, D, L.s_proj, 0, (float*)(ws + L.slab_proj), sB));                 // B3
-    }
-    if (!a3_fused)
-      RUN(rovit_gemm_nt(xmid, D, q + P.wprojT, D, M, D, D, nullptr, EPI_BF16, ws + L.dO, D, nullptr, nullptr, 0, nullptr, 0, nullptr, 0,
-                        sA));                                                                                        // A3
+    RUN(issue_merged(i, pending, xin, dp, xmid));
+    RUN(rovit_gemm_nt(xmid, D, q + P.wprojT, D, M, D, D, nullptr, EPI_BF16, ws + L.dO, D, nullptr, nullptr, 0, nullptr, 0, nullptr, 0,
+                      sA));                                                                                        // A3
     RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, dq, batch, T, H, D / H, 0.125f, sA));       // A4
     // qkv dgrad fused with the backward of norm1
     RUN(rovit_gemm_ln_bwd(dq, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), dX, xout, sA));      // A5
@@ -686,11 +557,10 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
   bool patch_done = false;
   if (pending >= 0) {
     if (ss && !hand_over(ss, sA, sB)) EVFAIL("event hand-over");
-    RUN(issue_b45(pending));
+    RUN(issue_qkv(pending));
     // the patch-embedding weight gradient (58 us, needs only the dgrad chain's final dX) runs on the caller's stream BESIDE block 0's
     // last weight gradients on the side stream instead of behind the join
-    static const bool patch_overlap = !(getenv("ROVIT_PATCH_OVERLAP") && getenv("ROVIT_PATCH_OVERLAP")[0] == '0');
-    if (ss && last_block == 0 && patch_overlap) { RUN(patch_grads()); patch_done = true; }
+    if (ss && last_block == 0) { RUN(patch_grads()); patch_done = true; }
     if (ss && defer_join && last_block > 0) {
       // the gradients of this range are final once B drains: tell the caller's reduction stream, do not stall A
       if (!hand_over(ss, sB, notify)) EVFAIL("event hand-over");
@@ -707,8 +577,9 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
 
 extern "C" int rovit_vit_backward(const float* images, const float* d_features, const float* const* params, const void* prep,
                                   void* workspace, float* const* grads, int batch, int depth, int first_block, int last_block,
-                                  rovit_stream_t stream) {
-  return vit_backward_impl(images, d_features, params, prep, workspace, grads, batch, depth, first_block, last_block, stream, false, nullptr);
+                                  int mlp_path, rovit_stream_t stream) {
+  return vit_backward_impl(images, d_features, params, prep, workspace, grads, batch, depth, first_block, last_block, mlp_path, stream, false,
+                           nullptr);
 }
 
 // Same, for a data-parallel caller that reduces each block range while the next one runs: for last_block > 0 the
@@ -717,8 +588,7 @@ extern "C" int rovit_vit_backward(const float* images, const float* d_features, 
 // last_block == 0, whose call joins everything into `stream`.
 extern "C" int rovit_vit_backward_notify(const float* images, const float* d_features, const float* const* params, const void* prep,
                                          void* workspace, float* const* grads, int batch, int depth, int first_block,
-                                         int last_block, rovit_stream_t stream, rovit_stream_t notify_stream) {
-  return vit_backward_impl(images, d_features, params, prep, workspace, grads, batch, depth, first_block, last_block, stream, true,
+                                         int last_block, int mlp_path, rovit_stream_t stream, rovit_stream_t notify_stream) {
+  return vit_backward_impl(images, d_features, params, prep, workspace, grads, batch, depth, first_block, last_block, mlp_path, stream, true,
                            (hipStream_t)notify_stream);
 }
-

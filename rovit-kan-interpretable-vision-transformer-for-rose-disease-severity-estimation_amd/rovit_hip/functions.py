@@ -246,6 +246,8 @@ class MLPHeadFn(torch.autograd.Function):
 class VitEngine:
     """Owns the device buffers of one backbone instance: prepared bf16 weights, activation workspaces and the
     flat gradient buffer.  One engine per DeiTTinyBackbone module."""
+    # mlp_path of engines that do not set their own (tests run the small parity cases through BOTH MLP-half paths by changing this)
+    default_mlp_path = native.MLP_AUTO
 
     def __init__(self, depth: int):
         self.depth = depth
@@ -265,6 +267,9 @@ class VitEngine:
         self.pre_backward_hook = None    # called as hook(engine) when the backbone's backward starts (head/KAN grads are final)
         # explainability: {block: callback(block, dL/d(norm1 output))}, set by DeiTTiny.forward for the next forward only
         self.grad_taps = {}
+        # which kernels run the MLP half (native.MLP_AUTO: by size; tests force MLP_TWO_LAUNCH / MLP_ONE_LAUNCH): an ARGUMENT of the
+        # forward and backward calls -- the forward's choice is saved with the graph, so a later change cannot split a step
+        self.mlp_path: Optional[int] = None          # None: VitEngine.default_mlp_path
         self.last_ws = None              # (workspace, batch) of the most recent training-mode forward (read by rovit_hip.taps)
 
     # -- prepared weights ---------------------------------------------------------------------
@@ -327,16 +332,17 @@ class VitFn(torch.autograd.Function):
         ws = engine.take_ws(B, need_bwd, dev)
         feats = torch.empty(B, 192, device=dev, dtype=torch.float32)
         parr = ptr_array(params)
+        mlp_path = int(engine.mlp_path if engine.mlp_path is not None else VitEngine.default_mlp_path)
         call('rovit_vit_forward', ptr(images), parr, ptr(engine.prep), ptr(ws), ptr(feats), B, engine.depth,
-             int(need_bwd), stream_ptr())
-        ctx.engine, ctx.batch, ctx.need_bwd = engine, B, need_bwd
+             int(need_bwd), mlp_path, stream_ptr())
+        ctx.engine, ctx.batch, ctx.need_bwd, ctx.mlp_path = engine, B, need_bwd, mlp_path
         if need_bwd:
             ctx.ws = ws
             ctx.save_for_backward(images)           # the patch-embedding weight gradient gathers its pixels from the batch itself
             ctx.params = params
             ctx.prep_key = engine._prep_key       # (data_ptr, version) of every parameter the bf16 weights were built from
             ctx.grad_taps = dict(engine.grad_taps)
-            engine.last_ws = (ws, B)
+            engine.last_ws = (ws, B, mlp_path)
         else:
             engine.give_ws(B, need_bwd, ws)
         return feats
@@ -388,11 +394,11 @@ class VitFn(torch.autograd.Function):
             if hooked and engine.notify_stream is not None and last > 0:
                 # the range's gradients become visible on the reduction stream; this stream is not stalled
                 call('rovit_vit_backward_notify', ptr(images), ptr(dfeat), parr, ptr(engine.prep), ptr(ctx.ws), garr, ctx.batch, depth,
-                     first, last, stream_ptr(), engine.notify_stream.cuda_stream)
+                     first, last, ctx.mlp_path, stream_ptr(), engine.notify_stream.cuda_stream)
                 engine.range_hook(engine, first, last, True)
             else:
                 call('rovit_vit_backward', ptr(images), ptr(dfeat), parr, ptr(engine.prep), ptr(ctx.ws), garr, ctx.batch, depth,
-                     first, last, stream_ptr())
+                     first, last, ctx.mlp_path, stream_ptr())
                 if hooked:
                     engine.range_hook(engine, first, last, False)
                 if last in grad_taps:

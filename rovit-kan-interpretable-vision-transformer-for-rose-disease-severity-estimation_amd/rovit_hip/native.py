@@ -15,9 +15,14 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get('ROVIT_HIP_LIB') or os.path.join(_PKG_ROOT, 'lib', 'librovit_hip.so')   # env override: developer A/B builds
 
 _lib: Optional[C.CDLL] = None
-ABI_VERSION = 303          # rovit_version() this binding matches (csrc/api.hip)
+ABI_VERSION = 400          # rovit_version() this binding matches (csrc/api.hip)
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# mlp_path of rovit_vit_forward / rovit_vit_backward (include/rovit_hip.h); rovit_gemm_nt's per-call tile flags
+MLP_AUTO, MLP_TWO_LAUNCH, MLP_ONE_LAUNCH = 0, 1, 2
+GEMM_TILED_192, GEMM_TILED_96 = 0x100, 0x200
+MLP_FUSED_MIN_ROWS = 34000          # ROVIT_MLP_AUTO's threshold (csrc/vit.hip): one-launch MLP half from this many token rows
 
 # name -> (restype, argtypes); mirrors include/rovit_hip.h one to one
 SIGNATURES = {
@@ -43,29 +48,20 @@ SIGNATURES = {
     'rovit_vit_forward_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     'rovit_vit_workspace_field': (_i, [_i, _i, _i, _i, _vp, _vp]),
     'rovit_vit_prepare': (_i, [_vp, _vp, _i, _vp]),
-    'rovit_vit_forward': (_i, [_vp] * 5 + [_i] * 3 + [_vp]),
+    'rovit_vit_forward': (_i, [_vp] * 5 + [_i] * 4 + [_vp]),
     'rovit_vit_forward_taps': (_i, [_vp] * 7 + [_i, _i, _vp]),
     'rovit_attention_probs': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
-    'rovit_vit_backward': (_i, [_vp] * 6 + [_i] * 4 + [_vp]),
-    'rovit_vit_backward_notify': (_i, [_vp] * 6 + [_i] * 4 + [_vp] + [_vp]),
+    'rovit_vit_backward': (_i, [_vp] * 6 + [_i] * 5 + [_vp]),
+    'rovit_vit_backward_notify': (_i, [_vp] * 6 + [_i] * 5 + [_vp] + [_vp]),
     'rovit_gemm_nt': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
-    'rovit_gemm_mlp_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     'rovit_gemm_resid_ln': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp]),
     'rovit_mlp_stream_bytes': (_sz, []),
     'rovit_mlp_prepare_stream': (_i, [_vp, _vp, _vp, _vp]),
     'rovit_mlp_fused_fwd': (_i, [_vp] * 9 + [_f, _i, _i, _vp]),
     'rovit_mlp_prepare_stream_tail': (_i, [_vp] * 6),
     'rovit_block_tail_fwd': (_i, [_vp] * 14 + [_f, _i, _i, _vp]),
-    'rovit_mlp_prepare_stream_tail_bwd': (_i, [_vp] * 5),
-    'rovit_block_tail_bwd': (_i, [_vp] * 9 + [_i, _vp]),
     'rovit_mlp_fused_bwd': (_i, [_vp] * 8 + [_i, _vp]),
-    'rovit_set_mlp_waves': (_i, [_i]),
-    'rovit_set_mlp_debug': (_i, [_i]),
-    'rovit_set_mlp_fused_min_rows': (_i, [_i]),
     'rovit_gemm_ln_bwd': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    'rovit_set_gemm_tile': (_i, [_i]),
-    'rovit_set_gemm_debug': (_i, [_i]),
-    'rovit_set_wgrad_tile': (_i, [_i, _i]),
     'rovit_wgrad_splits': (_i, [_i, _i, _i]),
     'rovit_wgrad_workspace_bytes': (_sz, [_i, _i, _i]),
     'rovit_wgrad': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -93,6 +89,14 @@ SIGNATURES = {
 }
 
 
+# entry points only the developer library exports (round-2 / round-3 experiments that lost; tools/ A/B them)
+DEV_SIGNATURES = {
+    'rovit_gemm_mlp_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    'rovit_mlp_prepare_stream_tail_bwd': (_i, [_vp] * 5),
+    'rovit_block_tail_bwd': (_i, [_vp] * 9 + [_i, _vp]),
+}
+
+
 class RovitHipError(RuntimeError):
     pass
 
@@ -111,6 +115,9 @@ def load() -> C.CDLL:
             fn.restype, fn.argtypes = res, args
         if hasattr(lib, 'rovit_dev_set_knob'):           # developer library (make -C csrc dev; tools/ only)
             lib.rovit_dev_set_knob.restype, lib.rovit_dev_set_knob.argtypes = _i, [_i, _i, _i]
+            for name, (res, args) in DEV_SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype, fn.argtypes = res, args
             # A/B of whole steps with the developer library: ROVIT_DEV_KNOBS="id=value,id=value" (common.h RovitKnob ids).
             # The product library exports no such entry point, so the variable does nothing there.
             for kv in filter(None, os.environ.get('ROVIT_DEV_KNOBS', '').split(',')):

@@ -54,12 +54,19 @@ _FIELD_DTYPE = {WS_XHAT1: (torch.bfloat16, 192), WS_QKV: (torch.bfloat16, 576), 
                 WS_RSTD1: (torch.float32, 1), WS_RSTD2: (torch.float32, 1)}
 
 
-def workspace_view(ws: torch.Tensor, batch: int, depth: int, field: int, block: int) -> torch.Tensor:
-    """Zero-copy (M, width) view of one saved buffer of a training workspace."""
+def workspace_view(ws: torch.Tensor, batch: int, depth: int, field: int, block: int, mlp_path: int = native.MLP_AUTO) -> torch.Tensor:
+    """(M, width) view of one saved buffer of a training workspace -- zero-copy, except WS_ACT when the one-launch MLP half wrote it
+    (mlp_path of the forward, see include/rovit_hip.h): that buffer is CHUNK-MAJOR [24][M][32] and is de-interleaved into a row-major
+    copy here (round 3 returned the raw bytes under a row-major shape)."""
     off, nbytes = ctypes.c_size_t(), ctypes.c_size_t()
     call('rovit_vit_workspace_field', batch, depth, field, block, ctypes.byref(off), ctypes.byref(nbytes))
     dt, width = _FIELD_DTYPE[field]
-    return ws[off.value:off.value + nbytes.value].view(dt).view(batch * 197, width)
+    M = batch * 197
+    flat = ws[off.value:off.value + nbytes.value].view(dt)
+    if field == WS_ACT and (mlp_path == native.MLP_ONE_LAUNCH or (mlp_path == native.MLP_AUTO and M >= native.MLP_FUSED_MIN_ROWS)) \
+            and block != depth - 1:            # (the last block's MLP half runs on the CLS rows with the two-launch kernels: row-major)
+        return flat.view(24, M, 32).permute(1, 0, 2).reshape(M, width)
+    return flat.view(M, width)
 
 
 def norm1_output(model, block: int) -> torch.Tensor:
@@ -69,7 +76,7 @@ def norm1_output(model, block: int) -> torch.Tensor:
     eng = model.engine
     if eng.last_ws is None:
         raise native.RovitHipError('norm1_output: no training-mode forward is pending (run the model with grad enabled first)')
-    ws, B = eng.last_ws
+    ws, B = eng.last_ws[:2]
     blk = model.blocks[block]
     xhat = workspace_view(ws, B, eng.depth, WS_XHAT1, block)
     return (xhat.float() * blk.norm1.weight.detach() + blk.norm1.bias.detach()).view(B, 197, 192)

@@ -186,11 +186,10 @@ def _gemm(native, A, W, bias, epi, **kw):
                 native.ptr(pos), kw.get('tokens', 0), native.stream_ptr())
 
 
-@pytest.mark.parametrize('tile', [0, 1])
+@pytest.mark.parametrize('tile', [0, 0x100, 0x200])      # weight-stationary kernels; ROVIT_GEMM_TILED_192 / _96: the LDS-tiled kernels, per call
 @pytest.mark.parametrize('M,N,K', [(394, 576, 192), (1000, 192, 768), (128, 768, 192), (77, 192, 576), (2561, 192, 192)])
 def test_gemm_bf16_bias(M, N, K, tile):
     native = _native()
-    native.call('rovit_set_gemm_tile', tile)
     torch.manual_seed(M + N + K)
     A = bf(torch.randn(M, K, device=dev()))
     W = bf(torch.randn(N, K, device=dev()) * 0.05)
@@ -199,13 +198,12 @@ def test_gemm_bf16_bias(M, N, K, tile):
     Ai = bf(torch.randint(-3, 4, (M, K), device=dev()).float())
     Wi = bf(torch.randint(-2, 3, (N, K), device=dev()).float())
     out = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
-    _gemm(native, Ai, Wi, None, 0, out=out)
+    _gemm(native, Ai, Wi, None, 0 | tile, out=out)
     ref = Ai.float() @ Wi.float().t()
     assert torch.equal(out.float(), bf(ref).float())
-    _gemm(native, A, W, bias, 0, out=out)
+    _gemm(native, A, W, bias, 0 | tile, out=out)
     ref = A.float() @ W.float().t() + bias
     assert relerr(out, ref) < 1e-2
-    native.call('rovit_set_gemm_tile', 0)
 
 
 def test_gemm_epilogues():

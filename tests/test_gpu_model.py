@@ -30,9 +30,11 @@ def mlp_half(request):
     """rovit_vit_forward / _backward pick the MLP-half kernels by batch size (one fused launch from 34 000 token rows, two launches
     below): the small parity cases run under BOTH so that the path of the benchmark batch is checked against the oracle too."""
     from rovit_hip import native
-    native.call('rovit_set_mlp_fused_min_rows', 0 if request.param == 'fused_mlp_half' else 1 << 30)
+    from rovit_hip.functions import VitEngine
+    # (round 4: `mlp_path` is an argument of the forward / backward calls, no longer a library-wide setter)
+    VitEngine.default_mlp_path = native.MLP_ONE_LAUNCH if request.param == 'fused_mlp_half' else native.MLP_TWO_LAUNCH
     yield request.param
-    native.call('rovit_set_mlp_fused_min_rows', 34000)
+    VitEngine.default_mlp_path = native.MLP_AUTO
 
 
 def _vit(depth, sd):

@@ -385,6 +385,8 @@ def test_mlp_backward_recompute_kernel_vs_torch(M, stride):
     derivative), ragged row counts, the strided CLS-row layout of the last block, and the headline size."""
     from rovit_hip import native
     from rovit_hip.native import call, ptr
+    if not hasattr(native.load(), 'rovit_gemm_mlp_bwd'):
+        pytest.skip("round 2's gelu'-recompute kernel lives in the developer library only since round 4 (it lost: 64 us against 40)")
     g = torch.Generator(device=dev()).manual_seed(M)
     bf = torch.bfloat16
     rows = M * stride
@@ -406,45 +408,6 @@ def test_mlp_backward_recompute_kernel_vs_torch(M, stride):
     assert float((got - ref).pow(2).mean().sqrt()) < 3e-3 * scale
     if stride > 1:                                              # rows between the strided ones are untouched
         assert bool((out[1:stride] == 7.0).all())
-
-
-def test_recompute_gelu_memory_mode_matches_the_default_path():
-    """ROVIT_RECOMPUTE_GELU=1 (gelu' recomputed in the backward instead of stored: 0.93 GB less workspace at batch 256)
-    is read once per process, so it runs in a child process; its features are bit-identical and its gradients agree
-    with the default path's to bf16 rounding of one tile (the recomputed gelu' is not rounded to bf16)."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-    code = r'''
-import sys, torch
-sys.path.insert(0, sys.argv[2]); sys.path.insert(0, sys.argv[3])
-from models.backbone import DeiTTiny
-from rovit_hip import native
-torch.manual_seed(0)
-m = DeiTTiny(2).to('cuda:0')
-x = torch.randn(5, 3, 224, 224, device='cuda:0')
-w = torch.randn(5, 192, device='cuda:0')
-f = m(x)
-(f * w).sum().backward()
-nb = native.load().rovit_vit_workspace_bytes(256, 12, 1)
-torch.save({'f': f.detach().cpu(), 'g': torch.cat([p.grad.flatten() for p in m.parameters()]).cpu(), 'ws': nb}, sys.argv[1])
-'''
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    pkg = os.path.join(root, 'rovit-kan-interpretable-vision-transformer-for-rose-disease-severity-estimation_amd')
-    res = {}
-    with tempfile.TemporaryDirectory() as td:
-        for mode in ('0', '1'):
-            out = os.path.join(td, f'm{mode}.pt')
-            env = dict(os.environ, ROVIT_RECOMPUTE_GELU=mode)
-            subprocess.run([sys.executable, '-c', code, out, root, pkg], check=True, env=env, timeout=300)
-            res[mode] = torch.load(out, weights_only=True)
-    assert torch.equal(res['0']['f'], res['1']['f'])
-    g0, g1 = res['0']['g'], res['1']['g']
-    assert float((g0 - g1).abs().max()) < 2e-2 * float(g0.abs().max())
-    assert float(torch.nn.functional.cosine_similarity(g0, g1, dim=0)) > 0.9999
-    saved = int(res['0']['ws']) - int(res['1']['ws'])
-    assert saved == 12 * ((256 * 197 * 768 * 2 + 255) // 256 * 256), saved
 
 
 @pytest.mark.parametrize('layers,num_knots,B', [([192, 64, 16, 1], 5, 8), ([192, 64, 16, 1], 5, 257), ([192, 64, 16, 1], 32, 512),

@@ -60,10 +60,22 @@ def _two_launch(native, xhat2, w1, w2, b1, b2, X0, keep=True):
     return act, dact, X, xhat, rstd
 
 
+KNOB_MLP_SCHEDULE = 8          # csrc/common.h RovitKnob: the schedules that lost live in the developer library only
+
+
+def _set_schedule(native, waves):
+    """10 = the product's schedule (nothing to set); 4 / 8 / 9 need the developer library (ROVIT_HIP_LIB=.../librovit_hip_dev.so)."""
+    lib = native.load()
+    if hasattr(lib, 'rovit_dev_set_knob'):
+        lib.rovit_dev_set_knob(KNOB_MLP_SCHEDULE, waves, 0)
+    elif waves != 10:
+        pytest.skip('schedule %d is compiled into the developer library only' % waves)
+
+
 def _fused(native, xhat2, w1, w2, b1, b2, X0, mode=2, ln=True, waves=None):
     M = xhat2.shape[0]
     if waves is not None:
-        native.call('rovit_set_mlp_waves', waves)
+        _set_schedule(native, waves)
     ws = torch.empty(native.load().rovit_mlp_stream_bytes(), dtype=torch.uint8, device=dev())
     native.call('rovit_mlp_prepare_stream', native.ptr(w1), native.ptr(w2), native.ptr(ws), native.stream_ptr())
     # poisoned outputs: a row or column the kernel fails to write shows up as NaN
@@ -89,7 +101,7 @@ def test_fused_mlp_half_equals_the_two_launch_path_and_a_torch_reference(M, wave
     prob = _mlp_problem(M, 100 + M)
     a0, d0, X0, h0, r0 = _two_launch(native, *prob)
     a1, d1, X1, h1, r1 = _fused(native, *prob, waves=waves)
-    native.call('rovit_set_mlp_waves', 10)     # the library default
+    _set_schedule(native, 10)     # the library default
     assert torch.equal(a0.view(torch.int16), a1.view(torch.int16))
     assert torch.equal(d0.view(torch.int16), d1.view(torch.int16))
     xhat2, w1, w2, b1, b2, Xin = prob
@@ -125,7 +137,7 @@ def test_pipelined_mlp_half_gelu_table_and_its_fallback_on_special_inputs(M):
     prob = (xhat2, w1, w2, b1, b2, X0)
     a0, d0, Xr, h0, r0 = _two_launch(native, *prob)
     a1, d1, X1, h1, r1 = _fused(native, *prob, waves=10)
-    native.call('rovit_set_mlp_waves', 10)
+    _set_schedule(native, 10)
     assert torch.equal(a0.view(torch.int16), a1.view(torch.int16))
     assert torch.equal(d0.view(torch.int16), d1.view(torch.int16))
     assert bool(torch.isfinite(X1).all())
@@ -136,7 +148,7 @@ def test_pipelined_mlp_half_gelu_table_and_its_fallback_on_special_inputs(M):
     prob = (xhat2, w1, w2, b1, b2, X0)
     a0, d0, Xr, h0, r0 = _two_launch(native, *prob)
     a1, d1, X1, h1, r1 = _fused(native, *prob, waves=10)
-    native.call('rovit_set_mlp_waves', 10)
+    _set_schedule(native, 10)
     assert torch.equal(a0.view(torch.int16), a1.view(torch.int16))
     assert torch.equal(d0.view(torch.int16), d1.view(torch.int16))
     assert float((X1 - Xr).abs().max()) < 2 ** -7 * max(float((X1 - X0).abs().max()), 1.0)
@@ -337,6 +349,8 @@ def test_block_tail_backward_equals_the_dgrad_launches_and_a_torch_reference(M):
     proj dgrad dO = dXb Wproj behind it in the same launch: dpre bit-identical, dX / dXb to the bf16 staging the other path has,
     dO against rovit_gemm_nt on this launch's own dXb (bit-identical: same MFMA chain) and all of it against fp32 torch."""
     native = _native()
+    if not hasattr(native.load(), 'rovit_block_tail_bwd'):
+        pytest.skip("round 3's backward block tail lives in the developer library only since round 4 (it lost in the step: 4.87 against 4.78 ms)")
     g = torch.Generator(device='cpu').manual_seed(1900 + M)
     r = lambda *s: torch.randn(*s, generator=g)
     dY = bf(r(M, 192)).to(dev())
@@ -475,37 +489,26 @@ def test_kan_stack_backward_in_two_launches_is_bit_identical_to_the_per_layer_ke
 
 
 def test_backbone_forward_with_the_fused_mlp_half_matches_the_two_launch_build_of_the_same_forward():
-    """ROVIT_MLP_FUSED=0 (read once per process) selects the two-launch MLP half: run both in subprocesses on the same seeded
-    weights and images, training workspaces, and compare features, every gradient and the saved act / gelu' of a block."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    pkg = os.path.join(root, 'rovit-kan-interpretable-vision-transformer-for-rose-disease-severity-estimation_amd')
-    code = r'''
-import sys, torch
-out, root, pkg = sys.argv[1:4]
-sys.path[:0] = [root, pkg]
-from oracle import ref_cpu
-from models.backbone import DeiTTiny
-m = DeiTTiny(12)
-m.load_state_dict(ref_cpu.init_vit_state(12, torch.Generator().manual_seed(5)))
-m = m.cuda().train()
-torch.manual_seed(1)
-x = torch.randn(24, 3, 224, 224, device='cuda')
-f = m(x)
-(f.float().square().mean()).backward()
-g = torch.cat([p.grad.flatten() for p in m.parameters()])
-torch.save({'f': f.detach().cpu(), 'g': g.cpu()}, out)
-'''
+    """mlp_path (an argument of rovit_vit_forward / _backward since round 4; rounds 2-3: a process-wide environment switch and two child
+    processes) selects the MLP-half kernels: run both on the same seeded weights and images, training workspaces, and compare features
+    and every gradient."""
+    from oracle import ref_cpu
+    from models.backbone import DeiTTiny
+    from rovit_hip import native
+    m = DeiTTiny(12)
+    m.load_state_dict(ref_cpu.init_vit_state(12, torch.Generator().manual_seed(5)))
+    m = m.cuda().train()
+    torch.manual_seed(1)
+    x = torch.randn(24, 3, 224, 224, device='cuda')
     res = {}
-    with tempfile.TemporaryDirectory() as td:
-        for mode in ('1', '0'):
-            out = os.path.join(td, f'o{mode}.pt')
-            env = dict(os.environ, ROVIT_MLP_FUSED=mode, ROVIT_MLP_BWD_FUSED=mode, ROVIT_MLP_FUSED_MIN_ROWS='0')
-            subprocess.run([sys.executable, '-c', code, out, root, pkg], check=True, env=env, timeout=600)
-            res[mode] = torch.load(out, weights_only=True)
+    for mode, path in (('1', native.MLP_ONE_LAUNCH), ('0', native.MLP_TWO_LAUNCH)):
+        m.engine.mlp_path = path
+        for prm in m.parameters():
+            prm.grad = None
+        f = m(x)
+        (f.float().square().mean()).backward()
+        res[mode] = {'f': f.detach().cpu(), 'g': torch.cat([prm.grad.flatten() for prm in m.parameters()]).cpu()}
+    m.engine.mlp_path = None
     f1, f0 = res['1']['f'], res['0']['f']
     g1, g0 = res['1']['g'], res['0']['g']
     # the two builds differ only by fp32 summation order inside fc2 (an occasional neighbouring-bf16 rounding of a branch output)

@@ -86,7 +86,7 @@ def test_two_stream_forward_equals_small_batch_chunks(B):
     # with the chunks on the default (two-launch) side.
     big = B * 197 >= 34000
     if big:
-        native.call('rovit_set_mlp_fused_min_rows', 0)
+        m.engine.mlp_path = native.MLP_ONE_LAUNCH
     try:
         f = m(x)
         (f * w).sum().backward()
@@ -103,7 +103,7 @@ def test_two_stream_forward_equals_small_batch_chunks(B):
             scale = float(g_big[n].abs().max()) + 1e-12
             assert float((p.grad - g_big[n]).abs().max()) <= 2e-3 * scale, n
     finally:
-        native.call('rovit_set_mlp_fused_min_rows', 34000)
+        m.engine.mlp_path = None
     if big:
         with torch.no_grad():
             f2 = torch.cat([m(x[i:i + 8]) for i in range(0, B, 8)])

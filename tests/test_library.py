@@ -36,6 +36,20 @@ def test_library_exports_every_declared_symbol(native):
     assert lib.rovit_version() >= 100
 
 
+def test_product_library_has_no_knobs(native):
+    """"re-entrant and thread-safe (no global mutable state besides a per-thread last-error string)".  Round 4: the
+    shipped library exports no setter and no developer entry point, and does not read the environment (the developer library,
+    `make -C csrc dev`, is where A/B switches and ablation bits live)."""
+    import subprocess
+    lib_path = os.path.join(os.path.dirname(native.LIB_PATH), 'librovit_hip.so')
+    dyn = subprocess.run(['nm', '-D', lib_path], capture_output=True, text=True, check=True).stdout
+    exported = [l.split()[-1] for l in dyn.splitlines() if ' T ' in l]
+    undefined = [l.split()[-1] for l in dyn.splitlines() if ' U ' in l]
+    assert not [e for e in exported if e.startswith('rovit_set_') or e.startswith('rovit_dev_')], exported
+    assert not [u for u in undefined if u.split('@')[0] in ('getenv', 'secure_getenv')], 'the product library reads the environment'
+    assert set(e for e in exported if e.startswith('rovit_')) == set(_header_symbols())
+
+
 def test_host_side_size_queries(native):
     lib = native.load()
     assert lib.rovit_vit_num_params(12) == 6 + 12 * 12

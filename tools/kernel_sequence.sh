@@ -1,9 +1,9 @@
 #!/bin/bash
-# Kernel launch sequence of one training step (single stream, so that the trace order is the program order): rocprofv3 --kernel-trace,
+# Kernel launch sequence of one training step (developer library, knob 4 = single stream, so that the trace order is the program order): rocprofv3 --kernel-trace,
 # then the names of the launches of the LAST step in start order.  usage: tools/kernel_sequence.sh  -> gpurun_out/kernel_sequence.txt
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 OUT=$PWD/gpurun_out
-ROVIT_SINGLE_STREAM=1 rocprofv3 --kernel-trace --output-format csv -d $OUT/kseq -o kseq -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/kseq.log 2>&1
+ROVIT_HIP_LIB=$PWD/rovit-kan-interpretable-vision-transformer-for-rose-disease-severity-estimation_amd/lib/librovit_hip_dev.so ROVIT_DEV_KNOBS=4=1 rocprofv3 --kernel-trace --output-format csv -d $OUT/kseq -o kseq -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/kseq.log 2>&1
 python3 - <<PY > $OUT/kernel_sequence.txt
 import csv, glob
 f = glob.glob("$OUT/kseq/**/*kernel_trace.csv", recursive=True)[0]

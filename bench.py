@@ -85,7 +85,7 @@ def _pmc_traffic(kernel_key):
     """HBM bytes per launch measured with rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 2x read
     correction) for `python bench.py --roofline-only` (tools/pmc_collect.py): read from the tracked
     profiles/r03_pmc_traffic.json (round 2's file as a fallback), or None."""
-    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 t = json.load(f).get(kernel_key, {}).get('traffic_bytes')
@@ -260,6 +260,54 @@ def wgrad_roofline(dev, iters=30):
             'avg_us': round(ms * 1e3, 2), 'avg_us_back_to_back': round(ms_train * 1e3, 2), 'algorithmic_bytes': alg_bytes,
             'traffic': _pmc_traffic('wgrad_kernel<192,192>'),
             'mfma_tflops': round(flops / (ms * 1e-3) / 1e12, 1)}
+
+
+def backbone_only(dev, batch=256, iters=10):
+    """BASELINE.json configs[1]: the DeiT-Tiny backbone alone at batch 256, bf16 -- inference forward and forward + backward with
+    the surrogate loss features.float().square().mean(), device events around whole passes."""
+    from models.backbone import DeiTTinyBackbone
+    torch.manual_seed(0)
+    bb = DeiTTinyBackbone(pretrained=False).to(dev)
+    x = torch.randn(batch, 3, 224, 224, device=dev)
+    bb.eval()
+    with torch.no_grad():
+        ms_f = _event_avg_ms(dev, lambda: bb(x), iters, per_launch=False)
+    bb.train()
+
+    def fb():
+        for p in bb.parameters():
+            p.grad = None
+        bb(x).float().square().mean().backward()
+    ms_fb = _event_avg_ms(dev, fb, iters, per_launch=False)
+    return {'batch': batch, 'fwd_inference_ms': round(ms_f, 3), 'fwd_inference_images_per_sec': round(batch / (ms_f * 1e-3), 1),
+            'fwd_bwd_ms': round(ms_fb, 3), 'fwd_bwd_images_per_sec': round(batch / (ms_fb * 1e-3), 1),
+            'fwd_mfma_frac_of_dense_bf16_peak': round(FWD_FLOP_PER_IMG * batch / (ms_f * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            'fwd_bwd_mfma_frac_of_dense_bf16_peak': round(TRAIN_FLOP_PER_IMG * batch / (ms_fb * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+
+
+def patch_roofline(dev):
+    """The PatchEmbed pair (timm PatchEmbed = conv k16 s16, reached through models/backbone.py:12-25) at batch 256: the forward GEMM
+    gathers its fp32 pixels from the NCHW images (154 MB read, 38.5 MB of token rows written), the weight gradient re-reads them."""
+    from rovit_hip import native
+    p, sp = native.ptr, native.stream_ptr()
+    lib = native.load()
+    B, T = 256, 197
+    img = torch.randn(B, 3, 224, 224, device=dev)
+    W = (torch.randn(192, 768, device=dev) * 0.03).to(torch.bfloat16)
+    bias, pos = torch.randn(192, device=dev) * 0.1, torch.randn(T, 192, device=dev) * 0.02
+    X = torch.empty(B * T, 192, device=dev)
+    dXb = torch.randn(B * T, 192, device=dev).to(torch.bfloat16)
+    M = B * (T - 1)
+    splits = lib.rovit_wgrad_splits(M, 192, 768)
+    ws = torch.empty(lib.rovit_wgrad_workspace_bytes(192, 768, splits), dtype=torch.uint8, device=dev)
+    res = {}
+    res['patch_embed_fwd'] = _entry(dev, lambda: lib.rovit_patch_embed_fwd(p(img), p(W), p(bias), p(pos), p(X), B, T, sp),
+                                    4.0 * B * 3 * 224 * 224 + 4.0 * M * 192 + 2.0 * 192 * 768, 2.0 * M * 192 * 768,
+                                    'gemm_ws_kernel<12,2,32,7>: PatchEmbed as a GEMM whose pixels are gathered from the fp32 images, M=50176 N=192 K=768', 'patch_embed_fwd')
+    res['patch_embed_wgrad'] = _entry(dev, lambda: lib.rovit_patch_embed_wgrad(p(dXb), 192, p(img), B, T, 192, splits, p(ws), sp),
+                                      4.0 * B * 3 * 224 * 224 + 2.0 * M * 192 + 4.0 * 192 * 768, 2.0 * M * 192 * 768,
+                                      'wgrad_kernel<192,96,true,true,2>: PatchEmbed weight gradient, pixels gathered again from the fp32 images', 'patch_embed_wgrad')
+    return res
 
 
 def fp32_mode(dev, batch=256, iters=5):
@@ -625,7 +673,7 @@ def main():
         dev = torch.device('cuda:0')
         _warm_clocks(dev)
         print(json.dumps({'roofline': wgrad_roofline(dev), 'roofline_attn': attn_roofline(dev), 'roofline_mlp': mlp_roofline(dev),
-                          'roofline_kan': kan_roofline(dev)}), flush=True)
+                          'roofline_kan': kan_roofline(dev), 'roofline_patch': patch_roofline(dev)}), flush=True)
         return
 
     launch_or_check_world(args, sys.argv[1:])            # returns only in a process that runs the benchmark itself
@@ -723,6 +771,8 @@ def main():
             res['roofline_mlp'] = mlp_roofline(dev)
             res['roofline_kan'] = kan_roofline(dev)
             res['fp32_mode'] = fp32_mode(dev)
+            res['roofline_patch'] = patch_roofline(dev)
+            res['backbone_only'] = backbone_only(dev)
             attn_us = sum(v['avg_us'] for v in res['roofline_attn'].values())
             attn_floor_us = sum(v['algorithmic_bytes'] for v in res['roofline_attn'].values()) / (HBM_PEAK_GBS * 1e9) * 1e6
             # images/sec as a fraction of the attention-GEMM roofline (north_star): the six attention kernels of one block

@@ -691,7 +691,9 @@ def main():
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        import datetime
+        # a collective that never completes must end the run with an error, not hold an 8-GPU lease until the driver's limit
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local), timeout=datetime.timedelta(minutes=4))
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 

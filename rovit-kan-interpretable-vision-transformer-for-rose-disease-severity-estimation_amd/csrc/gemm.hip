@@ -1740,6 +1740,9 @@ extern "C" int rovit_wgrad_reduce(const float* ws, int splits, int N, int K, con
 
 // reduce (and un-fold) up to ROVIT_REDUCE_BATCH weight gradients in two launches
 int rovit_wgrad_reduce_batch(const RovitReduceDesc* descs, int n, rovit_stream_t stream) {
+#ifdef ROVIT_DEV
+  if (ROVIT_KNOB(ROVIT_KNOB_SKIP_WGRAD_REDUCE, 0)) return ROVIT_OK;      // timing experiment only: gradients are wrong
+#endif
   ROVIT_CHECK_ARG(descs && n > 0 && n <= ROVIT_REDUCE_BATCH, ROVIT_ERR_SHAPE, "wgrad_reduce_batch: bad batch size %d", n);
   ReduceBatch rb{}, ab{};
   int blocks = 0, fblocks = 0;

@@ -381,7 +381,8 @@ def kan_roofline(dev, iters=30):
         res[key] = {'bound': 'hbm', 'kernel': kname,
                     'num_knots': G, 'batch': B, 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(gbs / HBM_PEAK_GBS, 5), 'avg_us': round(ms * 1e3, 2), 'algorithmic_bytes': alg,
-                    'traffic': _pmc_traffic(f'kan_stack_mfma_kernel<{4 if G == 5 else 18}>') if mfma else None}
+                    'traffic': _pmc_traffic(f'kan_stack_mfma_kernel<{4 if G == 5 else 18}>') if mfma else
+                    (_pmc_traffic('kan_fwd_' + key) if not fused else None)}
         # the honest compute roofline of this kernel class (121 FLOP/B against a 20 FLOP/B fp32 ridge): fp32
         # FLOPs on the USEFUL terms -- per (sample, input, output) the 4 live basis products + the Linear term -- against the
         # 157.3 TFLOP/s fp32 peak (vector = matrix rate on gfx950)

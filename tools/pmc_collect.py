@@ -1,7 +1,7 @@
 """PMC evidence for the roofline kernels (run on the GPU box): rocprofv3 --pmc passes over `python3 bench.py --roofline-only`,
 as MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE passes, nothing combined with trace domains, read
 bytes = 2 x FETCH_SIZE on gfx950 -- plus two SQ passes (matrix / vector / LDS activity) for the kernels whose bound is argued in
-DESIGN.md.  Writes gpurun_out/pmc_r03/r03_pmc_traffic.json and r03_pmc_sq.json (copy them to profiles/).
+DESIGN.md.  Writes gpurun_out/pmc_r04/r04_pmc_traffic.json and r04_pmc_sq.json (copy them to profiles/).
 
     python3 tools/pmc_collect.py [--skip-sq]
 
@@ -17,7 +17,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, 'gpurun_out', 'pmc_r03')
+OUT = os.path.join(ROOT, 'gpurun_out', 'pmc_r04')
 
 # (substring of rocprof's Kernel_Name, occurrence group ordered by first dispatch when the same kernel runs two shapes, key)
 KERNELS = [
@@ -34,6 +34,8 @@ KERNELS = [
     ('mlp_fused_kernel<0, 0, 8, false, true, false>', 0, 'mlp_fused_fwd_inference'),
     ('mlp_fused_kernel<1, 1, 8, false, false, false>', 0, 'mlp_fused_bwd'),
     ('kan_fwd_kernel', 0, 'kan_fwd_kernel'),
+    ('gemm_ws_kernel<12, 2, 32, 7>', 0, 'patch_embed_fwd'),
+    ('wgrad_kernel<192, 96, true, true, 2>', 0, 'patch_embed_wgrad'),
     ('kan_stack_mfma_kernel<4, 4', 0, 'kan_stack_mfma_kernel<4>'),
     ('kan_stack_mfma_kernel<18, 1', 0, 'kan_stack_mfma_kernel<18>'),
 ]
@@ -97,15 +99,30 @@ def main():
                 w_kb, n2 = wr[key]
                 res[key] = {'FETCH_SIZE_KB_mean': round(f_kb, 1), 'WRITE_SIZE_KB_mean': round(w_kb, 1), 'launches': [n1, n2],
                             'traffic_bytes': round((2 * f_kb + w_kb) * 1024), 'note': 'read bytes = 2 x FETCH_SIZE (gfx950), counters in KB'}
-    json.dump(res, open(os.path.join(OUT, 'r03_pmc_traffic.json'), 'w'), indent=1)
-    print(json.dumps({k: v['traffic_bytes'] for k, v in res.items()}, indent=1), 'rc', rc_f, rc_w)
+        # the per-layer KAN forward at the reference's own sizes: bench.py --roofline-only runs C5 (G = 32, batch 512) first and C3 (G = 5,
+        # batch 256) last, three kan_fwd_kernel launches each with their own grid: a configuration's traffic = the sum over its layers
+        def kan_groups(path, counter):
+            groups = collections.OrderedDict()
+            for r in csv.DictReader(open(path)):
+                if r['Counter_Name'] == counter and 'kan_fwd_kernel' in r['Kernel_Name']:
+                    groups.setdefault(r.get('Grid_Size', ''), []).append(float(r['Counter_Value']))
+            return [sum(v) / len(v) for v in groups.values()]
+        gf, gw = kan_groups(f_csv, 'FETCH_SIZE'), kan_groups(w_csv, 'WRITE_SIZE')
+        if len(gf) == 6 and len(gw) == 6:
+            for key, sl in (('kan_fwd_c5_g32_b512', slice(0, 3)), ('kan_fwd_c3_g5_b256', slice(3, 6))):
+                res[key] = {'FETCH_SIZE_KB_sum_of_3_layers': round(sum(gf[sl]), 1), 'WRITE_SIZE_KB_sum_of_3_layers': round(sum(gw[sl]), 1),
+                            'traffic_bytes': round((2 * sum(gf[sl]) + sum(gw[sl])) * 1024), 'note': 'three per-layer launches, read bytes = 2 x FETCH_SIZE'}
+        else:
+            res['kan_fwd_per_layer_note'] = 'expected 6 kan_fwd_kernel grid groups (C5 then C3), found %d / %d' % (len(gf), len(gw))
+    json.dump(res, open(os.path.join(OUT, 'r04_pmc_traffic.json'), 'w'), indent=1)
+    print(json.dumps({k: v['traffic_bytes'] for k, v in res.items() if isinstance(v, dict)}, indent=1), 'rc', rc_f, rc_w)
     if '--skip-sq' in sys.argv:
         return
     sq = {}
     for i, counters in enumerate(SQ_PASSES):
         rc, path = run_pass(f'sq{i}', counters)
         if not path:
-            sq[f'pass{i}_error'] = f'rocprofv3 rc {rc}: see gpurun_out/pmc_r03/sq{i}.log (a counter name may not exist on this ROCm)'
+            sq[f'pass{i}_error'] = f'rocprofv3 rc {rc}: see gpurun_out/pmc_r04/sq{i}.log (a counter name may not exist on this ROCm)'
             continue
         for c in counters:
             for key, (mean, n) in per_kernel(path, c).items():
@@ -121,7 +138,7 @@ def main():
                     v[c + '_share_of_wave_cycles'] = round(v[c] / wc, 4)
         if v.get('SQ_LDS_IDX_ACTIVE'):
             v['lds_bank_conflict_share_of_lds_cycles'] = round(v.get('SQ_LDS_BANK_CONFLICT', 0.0) / v['SQ_LDS_IDX_ACTIVE'], 4)
-    json.dump(sq, open(os.path.join(OUT, 'r03_pmc_sq.json'), 'w'), indent=1)
+    json.dump(sq, open(os.path.join(OUT, 'r04_pmc_sq.json'), 'w'), indent=1)
     print(json.dumps(sq, indent=1)[:3000])
 
 

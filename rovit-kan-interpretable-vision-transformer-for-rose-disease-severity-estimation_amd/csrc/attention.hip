@@ -455,7 +455,17 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_kernel(const AttnArgs a, 
       }
     }
   }
+  // pass 2's own Q / dO row fragments: the restage form takes them from the LDS tiles it is about to overwrite (round 4, first version: from
+  // global memory again -- PMC traffic 236 MB per launch against 155.5 algorithmic, half of the excess these 50 KB per item)
+  bf16x8 qf[2][2], gf[2][2];
   if (!SPLIT) {
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        qf[qt][ks] = row_frag(T0, 32 * w + 16 * qt + l15, ks, lg);
+        gf[qt][ks] = row_frag(T1, 32 * w + 16 * qt + l15, ks, lg);
+      }
     __syncthreads();                               // every wave is done with the Q / dO tiles
     stage_tile(T0, base + a.H * HD, ld, a.T, tid);
     stage_tile(T1, base + 2 * a.H * HD, ld, a.T, tid);
@@ -464,7 +474,6 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_kernel(const AttnArgs a, 
   if (!SPLIT || pass == 1) {
     // ---------------- pass 2: dQ for queries [32w, 32w+32), both 16-query sub-tiles in registers ----------------
     if (32 * w >= a.T || ATTN_DBG(a, 2)) return;       // wave-uniform; no barrier follows
-    bf16x8 qf[2][2], gf[2][2];
     float lq[2];
     f32x4 ndq[2];
 #pragma unroll
@@ -473,10 +482,12 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_kernel(const AttnArgs a, 
       lq[qt] = s_lse[qr];
       const float nd = s_del[qr];
       ndq[qt] = (f32x4){nd, nd, nd, nd};
+      if (SPLIT) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        qf[qt][ks] = global_row_frag(base, ld, qr, a.T, ks, lg);
-        gf[qt][ks] = global_row_frag(gbase, ldo, qr, a.T, ks, lg);
+        for (int ks = 0; ks < 2; ++ks) {
+          qf[qt][ks] = global_row_frag(base, ld, qr, a.T, ks, lg);
+          gf[qt][ks] = global_row_frag(gbase, ldo, qr, a.T, ks, lg);
+        }
       }
     }
     f32x4 dq[4][2];

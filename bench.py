@@ -157,9 +157,11 @@ def attn_roofline(dev):
     res['attention_bwd'] = _entry(dev, lambda: lib.rovit_attention_bwd(p(qkv), p(o), p(lse), p(dO), p(dqkv), B, T, H, 64, 0.125, sp),
                                   2.0 * M * 576 * 2 + 2.0 * M * 192 * 2 + 4.0 * B * H * T, 10.0 * B * H * T * T * 64,
                                   'attn_bwd_kernel: dQ, dK, dV with the probabilities recomputed on chip (algorithmic FLOPs: 5 products)', 'attention_bwd')
-    res['qkv_dgrad_ln_bwd'] = _entry(dev, lambda: lib.rovit_gemm_ln_bwd(p(dqkv), 576, p(wqkvT), 576, M, 576, p(xhat), p(rstd), p(dX), p(dXb), sp),
-                                     2.0 * M * 576 + 2.0 * M * 192 * 2 + 4.0 * M + 8.0 * M * 192 + 2.0 * 192 * 576, 2.0 * M * 576 * 192,
-                                     'gemm_kdma_kernel<18,6>: QKV dgrad + norm1 backward, M=50432 N=192 K=576', 'qkv_dgrad_ln_bwd')
+    dXin = dX.to(bf)
+    # round 4: the residual gradient enters and leaves as bf16 rows (the step's form): dqkv + xhat + incoming gradient read, bf16 rows written
+    res['qkv_dgrad_ln_bwd'] = _entry(dev, lambda: lib.rovit_gemm_ln_bwd(p(dqkv), 576, p(wqkvT), 576, M, 576, p(xhat), p(rstd), None, p(dXin), p(dXb), sp),
+                                     2.0 * M * 576 + 2.0 * M * 192 * 3 + 4.0 * M + 2.0 * 192 * 576, 2.0 * M * 576 * 192,
+                                     'gemm_kdma_kernel<18,6>: QKV dgrad + norm1 backward, bf16 residual gradient in and out, M=50432 N=192 K=576', 'qkv_dgrad_ln_bwd')
     return res
 
 
@@ -220,9 +222,10 @@ def mlp_roofline(dev):
         2.0 * M * 192 * 2 + 8.0 * M * 192 + 2.0 * M * 576 + 4.0 * M + tail_w, tail_flops,
         'mlp_fused_kernel<0,0,8,false,true,true>: the same, nothing kept (inference)', 'block_tail_inference')
     dact.uniform_(0, 1)
-    res['fused_bwd'] = _entry(dev, lambda: lib.rovit_mlp_fused_bwd(p(dY), p(wsb), p(dact), p(dpre), p(xhat2), p(rstd), p(dX), p(dXb), M, sp),
-                              2.0 * M * 192 * 3 + 2.0 * M * 768 * 2 + 8.0 * M * 192 + 4.0 * M + wbytes, 4.0 * M * 768 * 192,
-                              'mlp_fused_kernel<1,1,8>: fc2 dgrad x gelu\' + fc1 dgrad + norm2 backward, dpre written once, M=50432', 'mlp_fused_bwd')
+    # round 4: dX = NULL -- the residual gradient travels in bf16 (dY is the incoming gradient; read once more by the row pass: L2)
+    res['fused_bwd'] = _entry(dev, lambda: lib.rovit_mlp_fused_bwd(p(dY), p(wsb), p(dact), p(dpre), p(xhat2), p(rstd), None, p(dXb), M, sp),
+                              2.0 * M * 192 * 3 + 2.0 * M * 768 * 2 + 4.0 * M + wbytes, 4.0 * M * 768 * 192,
+                              'mlp_fused_kernel<1,1,8>: fc2 dgrad x gelu\' + fc1 dgrad + norm2 backward, dpre written once, bf16 residual gradient, M=50432', 'mlp_fused_bwd')
     return res
 
 

@@ -219,12 +219,16 @@ int rovit_block_tail_fwd(const void* o, const void* wstream, const float* bp, co
  *   dX (M,192) += rstd2 (g - mean(g) - xhat2 mean(g xhat2)),  g = dpre W1T^T;   dXb = bf16(dX)     (= rovit_gemm_ln_bwd)
  * wstream_bwd: rovit_mlp_prepare_stream(w1f := W2T bf16 (768,192), w2 := W1T bf16 (192,768), norm2 affine folded in).
  * dact (input) and dpre (output) are chunk-major [24][M][32] like the forward's act / dact; rovit_wgrad_multi_ex reads them as such. */
+/* dX == NULL (round 4, what rovit_vit_backward does): the residual gradient travels in bf16 -- the incoming gradient is dY itself,
+ * dXb = bf16(float(dY) + the LayerNorm-backward term), and no fp32 dX is read or written. */
 int rovit_mlp_fused_bwd(const void* dY, const void* wstream_bwd, const void* dact, void* dpre, const void* xhat2, const float* rstd2,
                         float* dX, void* dXb, int M, rovit_stream_t stream);
 /* dgrad through a Linear that follows a LayerNorm, fused with that LayerNorm's backward:
- * dxhat = dY W^T;  dX += rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat));  dXb = bf16(dX) */
+ * dxhat = dY W^T;  dX += rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat));  dXb = bf16(dX).
+ * dXb_in != NULL (round 4): the incoming residual gradient as bf16 rows (M,192); then dXb = bf16(float(dXb_in) + that term) and the fp32
+ * dX (may be NULL) is neither read nor written: 58 MB less per launch at batch 256. */
 int rovit_gemm_ln_bwd(const void* dY, int ldy, const void* W, int ldw, int M, int K, const void* xhat, const float* rstd, float* dX,
-                      void* dXb, rovit_stream_t stream);
+                      const void* dXb_in, void* dXb, rovit_stream_t stream);
 /* G(N,K) = dY(M,N)^T A(M,K) and colsum(dY), split over M into `splits` fp32 slabs inside ws */
 int rovit_wgrad_splits(int M, int N, int K);
 size_t rovit_wgrad_workspace_bytes(int N, int K, int splits);
@@ -267,9 +271,12 @@ int rovit_patch_embed_wgrad(const void* dY, int ldy, const float* images, int ba
 int rovit_cls_rows(const float* cls, const float* pos, float* X, int batch, int tokens, rovit_stream_t stream);
 int rovit_cls_norm_fwd(const float* X, const float* gamma, const float* beta, float* feat, float* xhat, float* rstd, int batch,
                        int tokens, float eps, rovit_stream_t stream);
+/* backward of the final LayerNorm on the class tokens: writes the CLS rows of dX (fp32) / dXb (bf16); zero_fill != 0 first zeroes both
+ * for all tokens (rovit_vit_backward passes 0: only CLS rows are read behind it) */
 int rovit_cls_norm_bwd(const float* dfeat, const float* xhat, const float* rstd, const float* gamma, float* dX, void* dXb,
-                       float* dgamma, float* dbeta, int batch, int tokens, rovit_stream_t stream);
-int rovit_pos_grad(const float* dX, float* dpos, float* dcls, int batch, int tokens, rovit_stream_t stream);
+                       float* dgamma, float* dbeta, int batch, int tokens, int zero_fill, rovit_stream_t stream);
+/* dpos[t] = sum over images of the token gradient, dcls = dpos[0]; the gradient as fp32 rows (dX) or bf16 rows (dXb): exactly one */
+int rovit_pos_grad(const float* dX, const void* dXb, float* dpos, float* dcls, int batch, int tokens, rovit_stream_t stream);
 int rovit_prep_weight(const float* W, const float* bias, const float* gamma, const float* beta, void* Wf, void* WfT,
                       float* bias_f, int N, int K, rovit_stream_t stream);
 

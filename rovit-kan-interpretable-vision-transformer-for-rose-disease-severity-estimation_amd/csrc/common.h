@@ -61,6 +61,7 @@ enum RovitKnob {
   ROVIT_KNOB_WGRAD_WGS = 11,     // workgroups the single-problem weight-gradient launch aims for (default 512)
   ROVIT_KNOB_KAN_MFMA_NS = 12,   // sample tiles per wave of the matrix-core KAN stack (default: by grid size)
   ROVIT_KNOB_KDMA = 13,          // 0: the register-staged kernels instead of gemm_kdma_kernel for the K = 576 dgrad
+  ROVIT_KNOB_SKIP_DX_FP32_STORE = 15, // 1: the LayerNorm-backward epilogues do not write the fp32 dX (gradients WRONG): bound of a bf16 residual-gradient stream
   ROVIT_KNOB_SKIP_WGRAD_REDUCE = 14,  // 1: the slab-reduce / affine-finalize launches are not issued (gradients WRONG): upper bound of what folding them away could gain
   ROVIT_KNOB_COUNT = 32
 };

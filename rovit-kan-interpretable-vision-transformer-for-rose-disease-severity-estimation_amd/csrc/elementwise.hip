@@ -198,7 +198,8 @@ __global__ __launch_bounds__(1024) void cls_ln_affine_grad_kernel(const float* _
 }
 
 // dpos[t,d] = sum_b dX[b,t,d];  dcls[d] = dpos[0,d]
-__global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__ dX, float* __restrict__ dpos,
+template <typename TX>      // float: the fp32 dX; bf16 (round 4): the bf16 residual gradient that left block 0
+__global__ __launch_bounds__(256) void pos_grad_kernel(const TX* __restrict__ dX, float* __restrict__ dpos,
                                                        float* __restrict__ dcls, int B, int T) {
   __shared__ float s_p[4][64];
   const int el = threadIdx.x & 63, bs = threadIdx.x >> 6;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__
   float s = 0.f;
   if (e < T * D) {
 #pragma unroll 16
-    for (int b = bs; b < B; b += 4) s += dX[(size_t)b * T * D + e];
+    for (int b = bs; b < B; b += 4) s += (float)dX[(size_t)b * T * D + e];
   }
   s_p[bs][el] = s;
   __syncthreads();
@@ -390,14 +391,18 @@ extern "C" int rovit_cls_norm_fwd(const float* X, const float* gamma, const floa
   return ROVIT_OK;
 }
 
-// zero-fills dX / dXb (all tokens), then writes the CLS rows; also dgamma / dbeta of the final norm
+// writes the CLS rows of dX / dXb (zero_fill != 0: after zero-filling both for all tokens); also dgamma / dbeta of the final norm.
+// rovit_vit_backward passes zero_fill = 0 (round 4): the last block's post-attention half reads CLS rows only, and the residual
+// gradient that the other rows need (zero) is the memset of ONE bf16 buffer there instead of 57 MB of fills here.
 extern "C" int rovit_cls_norm_bwd(const float* dfeat, const float* xhat, const float* rstd, const float* gamma, float* dX,
-                                  void* dXb, float* dgamma, float* dbeta, int batch, int tokens, rovit_stream_t stream) {
+                                  void* dXb, float* dgamma, float* dbeta, int batch, int tokens, int zero_fill, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(dfeat && xhat && rstd && gamma && dX && dXb, ROVIT_ERR_NULL, "cls_norm_bwd: null pointer");
-  const size_t n = (size_t)batch * tokens * D;
-  hipError_t e1 = hipMemsetAsync(dX, 0, n * sizeof(float), (hipStream_t)stream);
-  hipError_t e2 = hipMemsetAsync(dXb, 0, n * sizeof(bf16), (hipStream_t)stream);
-  ROVIT_CHECK_ARG(e1 == hipSuccess && e2 == hipSuccess, ROVIT_ERR_LAUNCH, "cls_norm_bwd: memset failed");
+  if (zero_fill) {
+    const size_t n = (size_t)batch * tokens * D;
+    hipError_t e1 = hipMemsetAsync(dX, 0, n * sizeof(float), (hipStream_t)stream);
+    hipError_t e2 = hipMemsetAsync(dXb, 0, n * sizeof(bf16), (hipStream_t)stream);
+    ROVIT_CHECK_ARG(e1 == hipSuccess && e2 == hipSuccess, ROVIT_ERR_LAUNCH, "cls_norm_bwd: memset failed");
+  }
   hipLaunchKernelGGL(cls_ln_bwd_kernel, dim3((batch + 15) / 16), dim3(256), 0, (hipStream_t)stream, dfeat, xhat, rstd, gamma, dX,
                      (bf16*)dXb, batch, tokens);
   ROVIT_CHECK_LAUNCH("cls_ln_bwd_kernel");
@@ -408,9 +413,12 @@ extern "C" int rovit_cls_norm_bwd(const float* dfeat, const float* xhat, const f
   return ROVIT_OK;
 }
 
-extern "C" int rovit_pos_grad(const float* dX, float* dpos, float* dcls, int batch, int tokens, rovit_stream_t stream) {
-  ROVIT_CHECK_ARG(dX && dpos && dcls, ROVIT_ERR_NULL, "pos_grad: null pointer");
-  hipLaunchKernelGGL(pos_grad_kernel, dim3((tokens * D + 63) / 64), dim3(256), 0, (hipStream_t)stream, dX, dpos, dcls, batch, tokens);
+// exactly one of dX (fp32) / dXb (bf16, round 4) is the gradient w.r.t. the embedded tokens (B*tokens, 192)
+extern "C" int rovit_pos_grad(const float* dX, const void* dXb, float* dpos, float* dcls, int batch, int tokens, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG((dX != nullptr) != (dXb != nullptr) && dpos && dcls, ROVIT_ERR_NULL, "pos_grad: pass exactly one of dX / dXb, and the outputs");
+  const dim3 grid((tokens * D + 63) / 64), block(256);
+  if (dX) hipLaunchKernelGGL(pos_grad_kernel<float>, grid, block, 0, (hipStream_t)stream, dX, dpos, dcls, batch, tokens);
+  else hipLaunchKernelGGL(pos_grad_kernel<bf16>, grid, block, 0, (hipStream_t)stream, (const bf16*)dXb, dpos, dcls, batch, tokens);
   ROVIT_CHECK_LAUNCH("pos_grad_kernel");
   return ROVIT_OK;
 }

@@ -56,6 +56,7 @@ struct GemmArgs {
   const float* pos; int tokens;
   int n_tiles;
   float* rstd_out; float eps;   // EPI_RESID_LN: statistics of the LayerNorm fused behind the residual add
+  const bf16* xprev;  // EPI_LNBWD, round 4: the incoming residual gradient as bf16 rows (ld 192); then xres is neither read nor written
   const float* img;   // EPI_PATCH_IMG: images (B,3,224,224) fp32; row m = (image, patch), column = c*256 + kh*16 + kw
 #ifdef ROVIT_DEV
   int dbg;            // developer library only (ROVIT_KNOB_GEMM_DBG): bit 0 skip epilogue stores, 1 skip MFMAs, 2 skip DMA, 3 skip GELU
@@ -458,12 +459,18 @@ __global__ __launch_bounds__(256 * WK, 2) void gemm_ws_kernel(const GemmArgs g, 
               bf16x4* bp = (bf16x4*)(g.out + (size_t)m * g.ldo);
 #pragma unroll
               for (int i = 0; i < 3; ++i) {
-                float4 x = xp[16 * i + c];
+                float4 x;
+                if (g.xprev) {                      // bf16 residual gradient in, bf16 out: the fp32 dX is not touched
+                  const bf16x4 pb = ((const bf16x4*)(g.xprev + (size_t)m * 192))[16 * i + c];
+                  x = make_float4((float)pb[0], (float)pb[1], (float)pb[2], (float)pb[3]);
+                } else {
+                  x = xp[16 * i + c];
+                }
                 x.x += r * (v[4 * i] - c1 - h[4 * i] * c2);
                 x.y += r * (v[4 * i + 1] - c1 - h[4 * i + 1] * c2);
                 x.z += r * (v[4 * i + 2] - c1 - h[4 * i + 2] * c2);
                 x.w += r * (v[4 * i + 3] - c1 - h[4 * i + 3] * c2);
-                xp[16 * i + c] = x;
+                if (!g.xprev) xp[16 * i + c] = x;
                 f32x4 t = {x.x, x.y, x.z, x.w};
                 bp[16 * i + c] = pack4(t);
               }
@@ -1030,8 +1037,14 @@ __global__ __launch_bounds__(768, 1) void gemm_kdma_kernel(const GemmArgs g, int
     const unsigned xoff = (unsigned)mc * (unsigned)g.ldx + 4u * pc;
     float* xrow = g.xres + xoff;
     constexpr bool PREFETCH = KT <= 18;                     // K = 768: 96 registers of W leave no room to hold them over the MFMAs
+    u32x2_t pv0, pv1, pv2;                                  // EPI_LNBWD with a bf16 residual gradient (g.xprev): its row instead of xo*
     auto load_inputs = [&]() {
-      xo0 = *(const f32x4*)xrow; xo1 = *(const f32x4*)(xrow + 64); xo2 = *(const f32x4*)(xrow + 128);
+      if (EPI == EPI_LNBWD && g.xprev) {
+        const bf16* prow_p = g.xprev + ((unsigned)mc * 192u + 4u * pc);
+        pv0 = *(const u32x2_t*)prow_p; pv1 = *(const u32x2_t*)(prow_p + 64); pv2 = *(const u32x2_t*)(prow_p + 128);
+      } else {
+        xo0 = *(const f32x4*)xrow; xo1 = *(const f32x4*)(xrow + 64); xo2 = *(const f32x4*)(xrow + 128);
+      }
       if (EPI == EPI_LNBWD) {
         const bf16* hrow = g.mul + ((unsigned)mc * (unsigned)g.ldm + 4u * pc);
         hx0 = *(const u32x2_t*)hrow; hx1 = *(const u32x2_t*)(hrow + 64); hx2 = *(const u32x2_t*)(hrow + 128);
@@ -1069,6 +1082,14 @@ __global__ __launch_bounds__(768, 1) void gemm_kdma_kernel(const GemmArgs g, int
         for (int e = 0; e < 4; ++e) v[4 * i + e] = (float)tv[e];
       }
       f32x4 xs[3] = {xo0, xo1, xo2};
+      if (EPI == EPI_LNBWD && g.xprev) {
+        const u32x2_t pvs[3] = {pv0, pv1, pv2};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const bf16x4 pb = __builtin_bit_cast(bf16x4, pvs[i]);
+          xs[i] = (f32x4){(float)pb[0], (float)pb[1], (float)pb[2], (float)pb[3]};
+        }
+      }
       f32x4* xp = (f32x4*)(g.xres + (unsigned)mc * (unsigned)g.ldx);
       if (EPI == EPI_RESID_LN) {
         float sum = 0.f;
@@ -1114,8 +1135,10 @@ __global__ __launch_bounds__(768, 1) void gemm_kdma_kernel(const GemmArgs g, int
 #pragma unroll
             for (int e = 0; e < 4; ++e) xs[i][e] += rr * (v[4 * i + e] - c1 - (float)hb[e] * c2);
           }
+          if (!g.xprev && !GEMM_DBG(g, 64)) {
 #pragma unroll
-          for (int i = 0; i < 3; ++i) xp[16 * i + pc] = xs[i];
+            for (int i = 0; i < 3; ++i) xp[16 * i + pc] = xs[i];
+          }
 #pragma unroll
           for (int i = 0; i < 3; ++i) bp[16 * i + pc] = pack4(xs[i]);
         }
@@ -1795,15 +1818,19 @@ extern "C" int rovit_gemm_resid_ln(const void* A, int lda, const void* W, int ld
 
 // dgrad + LayerNorm backward: dxhat = dY(M,K) W(192,K)^T, then dX += rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)),
 // dXb = bf16(dX).  (W is the transposed folded weight, so the LayerNorm affine is already applied.)
+// dXb_in (round 4, may be NULL): the incoming residual gradient as bf16 rows (M,192).  Given, the launch computes
+// dXb = bf16(float(dXb_in) + LayerNorm-backward(dxhat)) and neither reads nor writes the fp32 dX (which may then be NULL): the residual
+// gradient travels between the kernels of rovit_vit_backward in bf16 (58 MB per launch less at batch 256), summed in fp32 inside each.
 extern "C" int rovit_gemm_ln_bwd(const void* dY, int ldy, const void* W, int ldw, int M, int K, const void* xhat, const float* rstd,
-                                 float* dX, void* dXb, rovit_stream_t stream) {
-  ROVIT_CHECK_ARG(dY && W && xhat && rstd && dX && dXb, ROVIT_ERR_NULL, "gemm_ln_bwd: null pointer");
+                                 float* dX, const void* dXb_in, void* dXb, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(dY && W && xhat && rstd && (dX || dXb_in) && dXb, ROVIT_ERR_NULL, "gemm_ln_bwd: null pointer");
+  ROVIT_CHECK_ARG(rovit_aligned16(dXb_in) && rovit_aligned16(dXb), ROVIT_ERR_ALIGN, "gemm_ln_bwd: alignment");
   ROVIT_CHECK_ARG(M > 0 && (K == 192 || K == 576 || K == 768), ROVIT_ERR_SHAPE, "gemm_ln_bwd: K must be 192/576/768 (got %d)", K);
   ROVIT_CHECK_ARG(ldy % 8 == 0 && ldw % 8 == 0 && rovit_aligned16(dY) && rovit_aligned16(W) && rovit_aligned16(dX), ROVIT_ERR_ALIGN,
                   "gemm_ln_bwd: alignment");
   GemmArgs g{};
   g.A = (const bf16*)dY; g.lda = ldy; g.W = (const bf16*)W; g.ldw = ldw; g.M = M; g.N = 192; g.K = K;
-  g.mul = (const bf16*)xhat; g.ldm = 192; g.pos = rstd; g.xres = dX; g.ldx = 192; g.out = (bf16*)dXb; g.ldo = 192; GEMM_SET_DBG(g, ROVIT_KNOB(ROVIT_KNOB_GEMM_DBG, 0));
+  g.mul = (const bf16*)xhat; g.ldm = 192; g.pos = rstd; g.xres = dX; g.ldx = 192; g.out = (bf16*)dXb; g.ldo = 192; g.xprev = (const bf16*)dXb_in; GEMM_SET_DBG(g, ROVIT_KNOB(ROVIT_KNOB_GEMM_DBG, 0) | (ROVIT_KNOB(ROVIT_KNOB_SKIP_DX_FP32_STORE, 0) ? 64 : 0));
   if (K == 192) return launch_ws<6, 1, 64>(g, EPI_LNBWD, (hipStream_t)stream);
   if (kdma_enabled() && K == 576) return launch_kdma<18, EPI_LNBWD>(g, (hipStream_t)stream);
   if (K == 576) return launch_ws<9, 2, 32>(g, EPI_LNBWD, (hipStream_t)stream);

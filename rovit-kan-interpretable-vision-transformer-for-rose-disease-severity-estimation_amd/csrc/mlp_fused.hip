@@ -840,8 +840,16 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
   float ra[4], rb[4];              // backward: rstd2
   auto fetch = [&](int pass, float4 (&xs)[3], bf16x4 (&hs)[3], float& rr) {
     const int mc = crow(pass);
+    if (KIND && !g.X) {                  // round 4: bf16 residual gradient -- the incoming gradient IS the launch's dY operand (row-major (M,192))
 #pragma unroll
-    for (int i = 0; i < 3; ++i) xs[i] = ((const float4*)(g.X + (size_t)mc * D))[16 * i + c16];
+      for (int i = 0; i < 3; ++i) {
+        const bf16x4 t = ((const bf16x4*)(g.xin + (size_t)mc * D))[16 * i + c16];
+        xs[i] = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) xs[i] = ((const float4*)(g.X + (size_t)mc * D))[16 * i + c16];
+    }
     if (KIND) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) hs[i] = ((const bf16x4*)(g.xhat + (size_t)mc * D))[16 * i + c16];
@@ -902,8 +910,10 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
       }
       if (owned(row, m)) {
         bf16x4* bp = (bf16x4*)(g.xb + (size_t)m * D);
+        if (g.X && !MLP_DBG(g, 64)) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) xp[16 * i + c16] = xs[i];
+          for (int i = 0; i < 3; ++i) xp[16 * i + c16] = xs[i];
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) bp[16 * i + c16] = bq[i];
       }
@@ -1227,7 +1237,8 @@ extern "C" int rovit_block_tail_fwd(const void* o, const void* wstream, const fl
 // rovit_mlp_prepare_stream builds from (w1f := W2T (768,192), w2 := W1T folded (192,768)).
 extern "C" int rovit_mlp_fused_bwd(const void* dY, const void* wstream_bwd, const void* dact, void* dpre, const void* xhat2,
                                    const float* rstd2, float* dX, void* dXb, int M, rovit_stream_t stream) {
-  ROVIT_CHECK_ARG(dY && wstream_bwd && dact && dpre && xhat2 && rstd2 && dX && dXb, ROVIT_ERR_NULL, "mlp_fused_bwd: null pointer");
+  // dX == NULL (round 4): the residual gradient travels in bf16 -- dXb = bf16(float(dY) + LayerNorm-2-backward(...)), no fp32 dX read or written
+  ROVIT_CHECK_ARG(dY && wstream_bwd && dact && dpre && xhat2 && rstd2 && dXb, ROVIT_ERR_NULL, "mlp_fused_bwd: null pointer");
   ROVIT_CHECK_ARG(M > 0 && (size_t)M * HID * 2 < ((size_t)1 << 31), ROVIT_ERR_SHAPE, "mlp_fused_bwd: M = %d out of range", M);
   ROVIT_CHECK_ARG(rovit_aligned16(dY) && rovit_aligned16(wstream_bwd) && rovit_aligned16(dact) && rovit_aligned16(dpre) &&
                       rovit_aligned16(xhat2) && rovit_aligned16(dX) && rovit_aligned16(dXb),
@@ -1236,7 +1247,7 @@ extern "C" int rovit_mlp_fused_bwd(const void* dY, const void* wstream_bwd, cons
   g.xin = (const bf16*)dY; g.wstream = (const bf16*)wstream_bwd; g.act = (bf16*)dpre; g.mul = (const bf16*)dact; g.X = dX;
   g.xhat = (bf16*)const_cast<void*>(xhat2); g.rstd = const_cast<float*>(rstd2); g.xb = (bf16*)dXb; g.M = M;
 #ifdef ROVIT_DEV
-  g.dbg = ROVIT_KNOB(ROVIT_KNOB_MLP_DBG, 0);
+  g.dbg = ROVIT_KNOB(ROVIT_KNOB_MLP_DBG, 0) | (ROVIT_KNOB(ROVIT_KNOB_SKIP_DX_FP32_STORE, 0) ? 64 : 0);
 #endif
   ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<1, 1, 8>, lds_bytes(1, 8)), ROVIT_ERR_LAUNCH,
                   "mlp_fused_bwd: cannot raise the LDS limit");
@@ -1261,7 +1272,7 @@ extern "C" int rovit_block_tail_bwd(const void* dY, const void* wstream_bwd, con
   g.wstream = (const bf16*)wstream_bwd + (size_t)(NCHUNK + PENTRIES) * CH_ELEMS;      // the backward block-tail image
   g.xhat = (bf16*)const_cast<void*>(xhat2); g.rstd = const_cast<float*>(rstd2); g.xb = (bf16*)dXb; g.M = M;
 #ifdef ROVIT_DEV
-  g.dbg = ROVIT_KNOB(ROVIT_KNOB_MLP_DBG, 0);
+  g.dbg = ROVIT_KNOB(ROVIT_KNOB_MLP_DBG, 0) | (ROVIT_KNOB(ROVIT_KNOB_SKIP_DX_FP32_STORE, 0) ? 64 : 0);
 #endif
   ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<1, 1, 8, false, false, true>, lds_bytes(1, 8)), ROVIT_ERR_LAUNCH,
                   "block_tail_bwd: cannot raise the LDS limit");

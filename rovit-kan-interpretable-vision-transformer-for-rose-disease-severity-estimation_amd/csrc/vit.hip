@@ -396,13 +396,18 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
   char* ws = (char*)workspace;
   const int M = (int)L.M;
   const bool one_launch = mlp_one_launch(mlp_path, M);       // the SAME decision the forward took (same argument, same row count)
-  float* dX = (float*)(ws + L.dX);
-  // bf16 copy of the residual-stream gradient ENTERING block i lives in x0[i % 3] (x0v(-1) feeds the patch embedding)
+  float* dX = (float*)(ws + L.dX);        // fp32, used on the CLS rows of the last block only (round 4)
+  // Round 4: the residual-stream gradient travels between the kernels in BF16 -- every LayerNorm-backward epilogue reads the incoming
+  // gradient's bf16 rows, adds its term in fp32 and writes bf16 rows; rounds 1-3 also read and wrote an fp32 dX per kernel (116 MB per
+  // block at batch 256 = 11 % of the backward's bytes; bound measured first, developer knob 15: 4.465 -> 4.33 ms with the fp32 stores
+  // alone skipped).  25 roundings to bf16 along the depth instead of fresh ones at every use: parameter gradients vs the fp32 oracle
+  // DESIGN.md section 2.
+  // The gradient ENTERING block i lives in x0[i % 3] (x0v(-1) feeds the patch embedding), the mid-block one in x1[i & 1].
   auto x0v = [&](int i) { return ws + L.x0[(i + 3) % 3]; };
   if (first_block == depth - 1) {
     ROVIT_CHECK_ARG(d_features, ROVIT_ERR_NULL, "vit_backward: null d_features");
     RUN(rovit_cls_norm_bwd(d_features, (const float*)(ws + L.xhat_cls), (const float*)(ws + L.rstd_cls), params[P_NORM_W], dX,
-                           x0v(depth - 1), grads[P_NORM_W], grads[P_NORM_B], batch, T, stream));
+                           x0v(depth - 1), grads[P_NORM_W], grads[P_NORM_B], batch, T, 0, stream));
   }
   // Two-stream schedule (see SideStream above).  Per block i (p = i & 1), stream A runs the dgrad chain
   //   A1 + A2 MLP half (fc2 dgrad * gelu' -> dpre[p]; fc1 dgrad + norm2 bwd -> dX, x1[p]): one launch from batch 173, else two
@@ -492,6 +497,8 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
                         MLP * rs, nullptr, 0, stream));
       RUN(rovit_gemm_nt(dp, MLP * rs, q + P.wfc1T, MLP, Mr, D, MLP, nullptr, EPI_BF16, ws + L.dxhat, D * rs, nullptr, nullptr, 0, nullptr, 0,
                         nullptr, 0, stream));
+      // the mid-block gradient of this block is zero except on the CLS rows: it is the qkv dgrad's incoming gradient for ALL rows below
+      ROVIT_CHECK_ARG(hipMemsetAsync(xmc, 0, (size_t)M * D * sizeof(bf16), sA) == hipSuccess, ROVIT_ERR_LAUNCH, "vit_backward: memset failed");
       RUN(rovit_layernorm_bwd_rows(ws + L.dxhat, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmc, batch, T, stream));
       // attention backward reads dO for every query: rows other than CLS carry no gradient (the proj dgrad below writes the CLS rows)
       ROVIT_CHECK_ARG(hipMemsetAsync(ws + L.dO, 0, (size_t)M * D * sizeof(bf16), sA) == hipSuccess, ROVIT_ERR_LAUNCH,
@@ -515,7 +522,7 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
         RUN(rovit_wgrad_reduce_batch(rd, 3, sB));
       }
       RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, dq, batch, T, H, D / H, 0.125f, stream));
-      RUN(rovit_gemm_ln_bwd(dq, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), dX, xout, stream));
+      RUN(rovit_gemm_ln_bwd(dq, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), nullptr, xmc, xout, stream));
       // the (full-size) qkv weight gradient of this block goes the way of every other block's: as `pending`, into the next block's
       // merged launch on the weight-gradient stream (or the flush behind the loop) instead of 50 us of serial work here
       pending = i;
@@ -531,11 +538,11 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
     // -- norm2 backward in registers and the proj dgrad in the same launch -- and measured it SLOWER in the step, 4.87 against 4.78 ms:
     // tools/attic)
     if (one_launch) {
-      RUN(rovit_mlp_fused_bwd(xin, q + P.wmlpb, s + L.dact, dp, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmid, M, sA));
+      RUN(rovit_mlp_fused_bwd(xin, q + P.wmlpb, s + L.dact, dp, s + L.xhat2, (const float*)(s + L.rstd2), nullptr, xmid, M, sA));
     } else {
       RUN(rovit_gemm_nt(xin, D, q + P.wfc2T, D, M, MLP, D, nullptr, EPI_MUL, dp, MLP, nullptr, nullptr, 0, s + L.dact, MLP, nullptr, 0, sA));   // A1
       // fc1 dgrad fused with the backward of norm2 (updates dX, writes its bf16 copy)
-      RUN(rovit_gemm_ln_bwd(dp, MLP, q + P.wfc1T, MLP, M, MLP, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmid, sA));            // A2
+      RUN(rovit_gemm_ln_bwd(dp, MLP, q + P.wfc1T, MLP, M, MLP, s + L.xhat2, (const float*)(s + L.rstd2), nullptr, xin, xmid, sA));   // A2
     }
     if (ss && !hand_over(ss, sA, sB)) EVFAIL("event hand-over");                                                   // E_i
     RUN(issue_merged(i, pending, xin, dp, xmid));
@@ -543,7 +550,7 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
                       sA));                                                                                        // A3
     RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, dq, batch, T, H, D / H, 0.125f, sA));       // A4
     // qkv dgrad fused with the backward of norm1
-    RUN(rovit_gemm_ln_bwd(dq, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), dX, xout, sA));      // A5
+    RUN(rovit_gemm_ln_bwd(dq, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), nullptr, xmid, xout, sA));   // A5
     pending = i;
   }
   auto patch_grads = [&]() -> int {          // the patch embedding's and the position embedding's gradients (block range ending at 0)
@@ -551,7 +558,7 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
     RUN(rovit_patch_embed_wgrad(x0v(-1), D, images, batch, T, D, L.s_pe, (float*)(ws + L.slab_pe), stream));
     RUN(rovit_wgrad_reduce((const float*)(ws + L.slab_pe), L.s_pe, D, PD, nullptr, nullptr, nullptr, grads[P_PATCH_W], grads[P_PATCH_B],
                            nullptr, nullptr, nullptr, stream));
-    RUN(rovit_pos_grad(dX, grads[P_POS], grads[P_CLS], batch, T, stream));
+    RUN(rovit_pos_grad(nullptr, x0v(-1), grads[P_POS], grads[P_CLS], batch, T, stream));
     return ROVIT_OK;
   };
   bool patch_done = false;

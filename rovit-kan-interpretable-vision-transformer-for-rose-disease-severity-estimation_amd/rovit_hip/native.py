@@ -61,7 +61,7 @@ SIGNATURES = {
     'rovit_mlp_prepare_stream_tail': (_i, [_vp] * 6),
     'rovit_block_tail_fwd': (_i, [_vp] * 14 + [_f, _i, _i, _vp]),
     'rovit_mlp_fused_bwd': (_i, [_vp] * 8 + [_i, _vp]),
-    'rovit_gemm_ln_bwd': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'rovit_gemm_ln_bwd': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'rovit_wgrad_splits': (_i, [_i, _i, _i]),
     'rovit_wgrad_workspace_bytes': (_sz, [_i, _i, _i]),
     'rovit_wgrad': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -77,8 +77,8 @@ SIGNATURES = {
     'rovit_patch_embed_wgrad': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     'rovit_cls_rows': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'rovit_cls_norm_fwd': (_i, [_vp] * 6 + [_i, _i, _f, _vp]),
-    'rovit_cls_norm_bwd': (_i, [_vp] * 8 + [_i, _i, _vp]),
-    'rovit_pos_grad': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    'rovit_cls_norm_bwd': (_i, [_vp] * 8 + [_i, _i, _i, _vp]),
+    'rovit_pos_grad': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     'rovit_prep_weight': (_i, [_vp] * 7 + [_i, _i, _vp]),
     'rovit_joint_loss': (_i, [_vp] * 14 + [_i, _i, _f, _f, _f, _f, _vp]),
     'rovit_scale_buffers': (_i, [_vp, _vp, _i, _vp, _vp]),

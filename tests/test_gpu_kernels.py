@@ -470,7 +470,7 @@ def test_gemm_ln_bwd_fused(M, K):
     dX = dX0.clone()
     dXb = torch.empty(M, 192, device=dev(), dtype=torch.bfloat16)
     native.call('rovit_gemm_ln_bwd', native.ptr(dY), K, native.ptr(W), K, M, K, native.ptr(xh), native.ptr(rstd), native.ptr(dX),
-                native.ptr(dXb), native.stream_ptr())
+                None, native.ptr(dXb), native.stream_ptr())
     g = bf(dY.float() @ W.float().t()).float()                        # the dgrad output, rounded as the kernel stages it
     h = xh.float()
     ref = dX0 + rstd[:, None] * (g - g.mean(1, keepdim=True) - h * (g * h).mean(1, keepdim=True))

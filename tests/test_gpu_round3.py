@@ -301,7 +301,7 @@ def test_fused_mlp_backward_equals_the_two_launch_dgrad_chain_and_a_torch_refere
     native.call('rovit_gemm_nt', p(dY), 192, p(w2t), 192, M, 768, 192, None, 3, p(dpre0), 768, None, None, 0, p(dact), 768, None, 0, sp)
     dXa = dX0.clone()
     dXba = torch.empty(M, 192, device=dev(), dtype=torch.bfloat16)
-    native.call('rovit_gemm_ln_bwd', p(dpre0), 768, p(w1t), 768, M, 768, p(xh), p(rstd), p(dXa), p(dXba), sp)
+    native.call('rovit_gemm_ln_bwd', p(dpre0), 768, p(w1t), 768, M, 768, p(xh), p(rstd), p(dXa), None, p(dXba), sp)
     # one launch
     ws = torch.empty(native.load().rovit_mlp_stream_bytes(), dtype=torch.uint8, device=dev())
     native.call('rovit_mlp_prepare_stream', p(w2t), p(w1t), p(ws), sp)

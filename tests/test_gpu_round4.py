@@ -99,3 +99,97 @@ def test_attention_backward_with_hugely_negative_logits_stays_finite():
     qf = qkv.float().requires_grad_(True)
     _attn_ref(qf, B, Tk, H).backward(dO.float())
     assert float((dqkv.float() - qf.grad).abs().max()) < 3e-2 * float(qf.grad.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Round 4: the residual gradient travels between the backward's kernels as bf16 rows (csrc/vit.hip); the kernels sum in fp32.
+# Arithmetic: autograd of timm Block (x = x + f(norm(x))): dX_out = dX_in + LayerNorm-backward(dgrad), reached through
+# /root/reference/models/backbone.py:23-25 and training/trainer.py:119,136.
+@pytest.mark.parametrize('M,K', [(394, 768), (1000, 576), (50, 192), (256 * 197, 576)])
+def test_gemm_ln_bwd_with_a_bf16_residual_gradient_equals_the_fp32_form_on_the_same_rounded_input(M, K):
+    """dXb_in given: dXb must be bit-identical to what the fp32 form produces from dX = float(dXb_in) (same arithmetic, same order:
+    only where the incoming rows come from differs), and the fp32 dX must stay untouched."""
+    native = _native()
+    torch.manual_seed(M * 3 + K)
+    dY = bf(torch.randn(M, K, device=dev()))
+    W = bf(torch.randn(192, K, device=dev()) * 0.05)
+    xh = bf(torch.randn(M, 192, device=dev()))
+    rstd = torch.rand(M, device=dev()) + 0.5
+    dXin = bf(torch.randn(M, 192, device=dev()))
+    p, sp = native.ptr, native.stream_ptr()
+    dX = dXin.float()
+    ref_b = torch.empty(M, 192, device=dev(), dtype=torch.bfloat16)
+    native.call('rovit_gemm_ln_bwd', p(dY), K, p(W), K, M, K, p(xh), p(rstd), p(dX), None, p(ref_b), sp)
+    guard = torch.full((M, 192), 7.0, device=dev())
+    out_b = torch.full((M, 192), float('nan'), device=dev(), dtype=torch.bfloat16)
+    native.call('rovit_gemm_ln_bwd', p(dY), K, p(W), K, M, K, p(xh), p(rstd), p(guard), p(dXin), p(out_b), sp)
+    assert torch.equal(out_b.view(torch.int16), ref_b.view(torch.int16))
+    assert bool((guard == 7.0).all())
+    out2 = torch.full((M, 192), float('nan'), device=dev(), dtype=torch.bfloat16)
+    native.call('rovit_gemm_ln_bwd', p(dY), K, p(W), K, M, K, p(xh), p(rstd), None, p(dXin), p(out2), sp)     # dX may be NULL
+    assert torch.equal(out2.view(torch.int16), ref_b.view(torch.int16))
+    g = bf(dY.float() @ W.float().t()).float()
+    h = xh.float()
+    ref = dXin.float() + rstd[:, None] * (g - g.mean(1, keepdim=True) - h * (g * h).mean(1, keepdim=True))
+    assert float((out_b.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())      # one bf16 rounding of the result
+
+
+@pytest.mark.parametrize('M', [1, 257, 1000, 256 * 197])
+def test_fused_mlp_backward_with_a_bf16_residual_gradient(M):
+    """rovit_mlp_fused_bwd with dX = NULL: the incoming gradient is dY itself; dXb bit-identical to the fp32 form started from
+    dX = float(dY), dpre unchanged."""
+    native = _native()
+    g = torch.Generator(device='cpu').manual_seed(77 + M)
+    r = lambda *s: torch.randn(*s, generator=g)
+    dY = bf(r(M, 192)).to(dev())
+    w2t = bf(r(768, 192) * 0.05).to(dev())
+    w1t = bf(r(192, 768) * 0.05).to(dev())
+    dact = bf(torch.rand(M, 768, generator=g) * 1.2 - 0.1).to(dev())
+    dact_c = dact.view(M, 24, 32).permute(1, 0, 2).contiguous().view(M, 768)
+    xh = bf(r(M, 192)).to(dev())
+    rstd = (torch.rand(M, generator=g) + 0.5).to(dev())
+    p, sp = native.ptr, native.stream_ptr()
+    ws = torch.empty(native.load().rovit_mlp_stream_bytes(), dtype=torch.uint8, device=dev())
+    native.call('rovit_mlp_prepare_stream', p(w2t), p(w1t), p(ws), sp)
+    outs = []
+    for mode in ('fp32', 'bf16'):
+        dpre = torch.full((M, 768), float('nan'), device=dev(), dtype=torch.bfloat16)
+        dXb = torch.full((M, 192), float('nan'), device=dev(), dtype=torch.bfloat16)
+        dX = dY.float() if mode == 'fp32' else None
+        native.call('rovit_mlp_fused_bwd', p(dY), p(ws), p(dact_c), p(dpre), p(xh), p(rstd), p(dX), p(dXb), M, sp)
+        outs.append((dpre, dXb))
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
+    assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
+    assert torch.isfinite(outs[1][1].float()).all()
+
+
+def test_pos_grad_from_bf16_rows_and_cls_norm_bwd_without_zero_fill():
+    native = _native()
+    B, T = 5, 197
+    torch.manual_seed(3)
+    p, sp = native.ptr, native.stream_ptr()
+    dXb = bf(torch.randn(B * T, 192, device=dev()))
+    dpos = torch.empty(T, 192, device=dev())
+    dcls = torch.empty(192, device=dev())
+    native.call('rovit_pos_grad', None, p(dXb), p(dpos), p(dcls), B, T, sp)
+    ref = dXb.float().view(B, T, 192).sum(0)
+    assert float((dpos - ref).abs().max()) < 1e-5 and torch.equal(dcls, dpos[0])
+    dpos2 = torch.empty_like(dpos)
+    native.call('rovit_pos_grad', p(dXb.float()), None, p(dpos2), p(dcls), B, T, sp)
+    assert torch.equal(dpos, dpos2)
+    with pytest.raises(native.RovitHipError):
+        native.call('rovit_pos_grad', None, None, p(dpos), p(dcls), B, T, sp)
+    # final-norm backward: zero_fill = 0 leaves the other rows alone, zero_fill = 1 zeroes them; CLS rows identical
+    dfeat = torch.randn(B, 192, device=dev())
+    xhat = torch.randn(B, 192, device=dev())
+    rstd = torch.rand(B, device=dev()) + 0.5
+    gamma = torch.randn(192, device=dev())
+    res = []
+    for zf in (1, 0):
+        dX = torch.full((B * T, 192), 3.0, device=dev())
+        dXo = torch.full((B * T, 192), 3.0, device=dev(), dtype=torch.bfloat16)
+        dg, db = torch.empty(192, device=dev()), torch.empty(192, device=dev())
+        native.call('rovit_cls_norm_bwd', p(dfeat), p(xhat), p(rstd), p(gamma), p(dX), p(dXo), p(dg), p(db), B, T, zf, sp)
+        res.append((dX.view(B, T, 192), dXo.view(B, T, 192)))
+    assert torch.equal(res[0][0][:, 0], res[1][0][:, 0]) and torch.equal(res[0][1][:, 0], res[1][1][:, 0])
+    assert bool((res[0][0][:, 1:] == 0).all()) and bool((res[1][0][:, 1:] == 3.0).all()) and bool((res[1][1][:, 1:].float() == 3.0).all())

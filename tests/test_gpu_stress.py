@@ -162,7 +162,7 @@ def test_fused_dgrad_layernorm_backward_gemm_is_reproducible_at_full_size(K):
     for rep in range(60):
         dx = x0.clone()
         dxb = torch.full((M, D), 7.0, device=dev(), dtype=torch.bfloat16)
-        call('rovit_gemm_ln_bwd', ptr(dy), K, ptr(w), K, M, K, ptr(xh), ptr(rstd), ptr(dx), ptr(dxb), native.stream_ptr())
+        call('rovit_gemm_ln_bwd', ptr(dy), K, ptr(w), K, M, K, ptr(xh), ptr(rstd), ptr(dx), None, ptr(dxb), native.stream_ptr())
         if ref is None:
             ref = (dx, dxb)
             g = dy.float() @ w.float().t()                                   # dxhat

@@ -14,5 +14,5 @@ for K in (192, 576, 768):
     X = torch.randn(M, D, device=dev); xh = torch.empty(M, D, device=dev, dtype=bf); rs = torch.rand(M, device=dev) + 0.5
     xb = torch.empty(M, D, device=dev, dtype=bf)
     t1 = timeit(lambda: call('rovit_gemm_resid_ln', ptr(A), K, ptr(W), K, M, K, ptr(b), ptr(X), ptr(xh), ptr(rs), 1e-6, sp), 30)
-    t2 = timeit(lambda: call('rovit_gemm_ln_bwd', ptr(A), K, ptr(W), K, M, K, ptr(xh), ptr(rs), ptr(X), ptr(xb), sp), 30)
+    t2 = timeit(lambda: call('rovit_gemm_ln_bwd', ptr(A), K, ptr(W), K, M, K, ptr(xh), ptr(rs), ptr(X), None, ptr(xb), sp), 30)
     print(f'K={K}: resid+LN {t1:6.1f} us   dgrad+LN-bwd {t2:6.1f} us', flush=True)

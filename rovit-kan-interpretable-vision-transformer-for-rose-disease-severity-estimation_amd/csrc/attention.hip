@@ -38,6 +38,7 @@ struct AttnArgs {
   float scale;
   // backward
   const bf16* dout;     // (B*T, H*64)
+  int dout_rows;        // rows of every image's dout that carry gradient (T; 1 = only the class token's: the last block, whose other rows are treated as zero and never read)
   bf16* dqkv;           // (B*T, 3*H*64)
 #ifdef ROVIT_DEV
   int dbg;              // developer library only (ROVIT_KNOB_ATTN_DBG, timing ablations): bit 0 skip pass 1, bit 1 skip pass 2
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_kernel(const AttnArgs a, 
   const bf16* obase = a.out + (size_t)b * a.T * ldo + h * HD;
   if (pass == 0) {
     stage_tile(T0, base, ld, a.T, tid);
-    stage_tile(T1, gbase, ldo, a.T, tid);
+    stage_tile(T1, gbase, ldo, a.dout_rows, tid);          // rows beyond dout_rows: zeros, not read
   } else {
     stage_tile(T0, base + a.H * HD, ld, a.T, tid);
     stage_tile(T1, base + 2 * a.H * HD, ld, a.T, tid);
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_kernel(const AttnArgs a, 
   {
     const int row = tid >> 1, half = tid & 1;     // 448 threads = 224 rows x 2 halves
     float d = 0.f;
-    if (row < a.T) {
+    if (row < a.dout_rows) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bf16x8 g = *(const bf16x8*)(gbase + (size_t)row * ldo + half * 32 + i * 8);
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_kernel(const AttnArgs a, 
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           qf[qt][ks] = global_row_frag(base, ld, qr, a.T, ks, lg);
-          gf[qt][ks] = global_row_frag(gbase, ldo, qr, a.T, ks, lg);
+          gf[qt][ks] = global_row_frag(gbase, ldo, qr, a.dout_rows, ks, lg);
         }
       }
     }
@@ -856,8 +857,15 @@ extern "C" int rovit_attention_fwd(const void* qkv, void* out, float* lse2, int 
   return ROVIT_OK;
 }
 
+// internal (common.h): dout_rows = rows of every image's dout that carry gradient; rows beyond are zeros that are never read
+int rovit_attention_bwd_rows(const void* qkv, const void* out, const float* lse2, const void* dout, int dout_rows, void* dqkv, int batch,
+                             int tokens, int heads, int head_dim, float scale, rovit_stream_t stream);
 extern "C" int rovit_attention_bwd(const void* qkv, const void* out, const float* lse2, const void* dout, void* dqkv, int batch,
                                    int tokens, int heads, int head_dim, float scale, rovit_stream_t stream) {
+  return rovit_attention_bwd_rows(qkv, out, lse2, dout, tokens, dqkv, batch, tokens, heads, head_dim, scale, stream);
+}
+int rovit_attention_bwd_rows(const void* qkv, const void* out, const float* lse2, const void* dout, int dout_rows, void* dqkv, int batch,
+                             int tokens, int heads, int head_dim, float scale, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(qkv && out && lse2 && dout && dqkv, ROVIT_ERR_NULL, "attention_bwd: null pointer");
   int rc = check_attn(batch, tokens, heads, head_dim);
   if (rc) return rc;
@@ -866,6 +874,8 @@ extern "C" int rovit_attention_bwd(const void* qkv, const void* out, const float
   AttnArgs a{};
   a.qkv = (const bf16*)qkv; a.out = (bf16*)out; a.lse2 = (float*)lse2; a.T = tokens; a.H = heads; a.scale = scale;
   a.dout = (const bf16*)dout; a.dqkv = (bf16*)dqkv;
+  ROVIT_CHECK_ARG(dout_rows >= 1 && dout_rows <= tokens, ROVIT_ERR_SHAPE, "attention_bwd: dout_rows out of range");
+  a.dout_rows = dout_rows;
 #ifdef ROVIT_DEV
   a.dbg = ROVIT_KNOB(ROVIT_KNOB_ATTN_DBG, 0);
 #endif

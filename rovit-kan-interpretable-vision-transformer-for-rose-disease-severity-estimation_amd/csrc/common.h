@@ -203,6 +203,12 @@ int rovit_layernorm_fwd_rows(const float* x, void* xhat, float* rstd, int rows, 
 int rovit_layernorm_bwd_rows(const void* dxhat, const void* xhat, const float* rstd, float* dX, void* dXb, int rows, int row_step,
                              rovit_stream_t stream);
 
+// attention backward whose dout carries gradient on the first `dout_rows` rows of every image only (the last block: the class token's)
+int rovit_attention_bwd_rows(const void* qkv, const void* out, const float* lse2, const void* dout, int dout_rows, void* dqkv, int batch,
+                             int tokens, int heads, int head_dim, float scale, rovit_stream_t stream);
+// rovit_gemm_ln_bwd with a bf16 residual gradient that is non-zero on every `cls_step`-th row only (other rows: zero, not read)
+int rovit_gemm_ln_bwd_cls(const void* dY, int ldy, const void* W, int ldw, int M, int K, const void* xhat, const float* rstd,
+                          const void* dXb_in, int cls_step, void* dXb, rovit_stream_t stream);
 // several weight gradients G[N][K] = dY[M][N]^T A[M][K] that share M, in one launch (gemm.hip)
 struct RovitWgradDesc { const void* dY; int ldy; const void* A; int lda; int N, K; float* ws; int a_blk, y_blk; };   // *_blk: operand chunk-major [cols/32][M][32]
 int rovit_wgrad_batch(const RovitWgradDesc* descs, int n, int M, int splits, rovit_stream_t stream);

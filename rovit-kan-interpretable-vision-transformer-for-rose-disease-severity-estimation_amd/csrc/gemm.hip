@@ -462,7 +462,8 @@ __global__ __launch_bounds__(256 * WK, 2) void gemm_ws_kernel(const GemmArgs g, 
                 float4 x;
                 if (g.xprev) {                      // bf16 residual gradient in, bf16 out: the fp32 dX is not touched
                   const bf16x4 pb = ((const bf16x4*)(g.xprev + (size_t)m * 192))[16 * i + c];
-                  x = make_float4((float)pb[0], (float)pb[1], (float)pb[2], (float)pb[3]);
+                  x = (g.tokens <= 0 || (m % g.tokens) == 0) ? make_float4((float)pb[0], (float)pb[1], (float)pb[2], (float)pb[3])
+                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {
                   x = xp[16 * i + c];
                 }
@@ -1084,10 +1085,11 @@ __global__ __launch_bounds__(768, 1) void gemm_kdma_kernel(const GemmArgs g, int
       f32x4 xs[3] = {xo0, xo1, xo2};
       if (EPI == EPI_LNBWD && g.xprev) {
         const u32x2_t pvs[3] = {pv0, pv1, pv2};
+        const bool has_in = g.tokens <= 0 || (mc % g.tokens) == 0;       // tokens > 0: only every tokens-th row carries an incoming gradient
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           const bf16x4 pb = __builtin_bit_cast(bf16x4, pvs[i]);
-          xs[i] = (f32x4){(float)pb[0], (float)pb[1], (float)pb[2], (float)pb[3]};
+          xs[i] = has_in ? (f32x4){(float)pb[0], (float)pb[1], (float)pb[2], (float)pb[3]} : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
       }
       f32x4* xp = (f32x4*)(g.xres + (unsigned)mc * (unsigned)g.ldx);
@@ -1821,8 +1823,19 @@ extern "C" int rovit_gemm_resid_ln(const void* A, int lda, const void* W, int ld
 // dXb_in (round 4, may be NULL): the incoming residual gradient as bf16 rows (M,192).  Given, the launch computes
 // dXb = bf16(float(dXb_in) + LayerNorm-backward(dxhat)) and neither reads nor writes the fp32 dX (which may then be NULL): the residual
 // gradient travels between the kernels of rovit_vit_backward in bf16 (58 MB per launch less at batch 256), summed in fp32 inside each.
+static int gemm_ln_bwd_impl(const void* dY, int ldy, const void* W, int ldw, int M, int K, const void* xhat, const float* rstd,
+                            float* dX, const void* dXb_in, int cls_step, void* dXb, rovit_stream_t stream);
 extern "C" int rovit_gemm_ln_bwd(const void* dY, int ldy, const void* W, int ldw, int M, int K, const void* xhat, const float* rstd,
                                  float* dX, const void* dXb_in, void* dXb, rovit_stream_t stream) {
+  return gemm_ln_bwd_impl(dY, ldy, W, ldw, M, K, xhat, rstd, dX, dXb_in, 0, dXb, stream);
+}
+int rovit_gemm_ln_bwd_cls(const void* dY, int ldy, const void* W, int ldw, int M, int K, const void* xhat, const float* rstd,
+                          const void* dXb_in, int cls_step, void* dXb, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(dXb_in && cls_step > 0, ROVIT_ERR_NULL, "gemm_ln_bwd_cls: needs the bf16 incoming gradient and a row step");
+  return gemm_ln_bwd_impl(dY, ldy, W, ldw, M, K, xhat, rstd, nullptr, dXb_in, cls_step, dXb, stream);
+}
+static int gemm_ln_bwd_impl(const void* dY, int ldy, const void* W, int ldw, int M, int K, const void* xhat, const float* rstd,
+                            float* dX, const void* dXb_in, int cls_step, void* dXb, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(dY && W && xhat && rstd && (dX || dXb_in) && dXb, ROVIT_ERR_NULL, "gemm_ln_bwd: null pointer");
   ROVIT_CHECK_ARG(rovit_aligned16(dXb_in) && rovit_aligned16(dXb), ROVIT_ERR_ALIGN, "gemm_ln_bwd: alignment");
   ROVIT_CHECK_ARG(M > 0 && (K == 192 || K == 576 || K == 768), ROVIT_ERR_SHAPE, "gemm_ln_bwd: K must be 192/576/768 (got %d)", K);
@@ -1830,7 +1843,7 @@ extern "C" int rovit_gemm_ln_bwd(const void* dY, int ldy, const void* W, int ldw
                   "gemm_ln_bwd: alignment");
   GemmArgs g{};
   g.A = (const bf16*)dY; g.lda = ldy; g.W = (const bf16*)W; g.ldw = ldw; g.M = M; g.N = 192; g.K = K;
-  g.mul = (const bf16*)xhat; g.ldm = 192; g.pos = rstd; g.xres = dX; g.ldx = 192; g.out = (bf16*)dXb; g.ldo = 192; g.xprev = (const bf16*)dXb_in; GEMM_SET_DBG(g, ROVIT_KNOB(ROVIT_KNOB_GEMM_DBG, 0) | (ROVIT_KNOB(ROVIT_KNOB_SKIP_DX_FP32_STORE, 0) ? 64 : 0));
+  g.mul = (const bf16*)xhat; g.ldm = 192; g.pos = rstd; g.xres = dX; g.ldx = 192; g.out = (bf16*)dXb; g.ldo = 192; g.xprev = (const bf16*)dXb_in; g.tokens = cls_step; GEMM_SET_DBG(g, ROVIT_KNOB(ROVIT_KNOB_GEMM_DBG, 0) | (ROVIT_KNOB(ROVIT_KNOB_SKIP_DX_FP32_STORE, 0) ? 64 : 0));
   if (K == 192) return launch_ws<6, 1, 64>(g, EPI_LNBWD, (hipStream_t)stream);
   if (kdma_enabled() && K == 576) return launch_kdma<18, EPI_LNBWD>(g, (hipStream_t)stream);
   if (K == 576) return launch_ws<9, 2, 32>(g, EPI_LNBWD, (hipStream_t)stream);

@@ -497,12 +497,9 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
                         MLP * rs, nullptr, 0, stream));
       RUN(rovit_gemm_nt(dp, MLP * rs, q + P.wfc1T, MLP, Mr, D, MLP, nullptr, EPI_BF16, ws + L.dxhat, D * rs, nullptr, nullptr, 0, nullptr, 0,
                         nullptr, 0, stream));
-      // the mid-block gradient of this block is zero except on the CLS rows: it is the qkv dgrad's incoming gradient for ALL rows below
-      ROVIT_CHECK_ARG(hipMemsetAsync(xmc, 0, (size_t)M * D * sizeof(bf16), sA) == hipSuccess, ROVIT_ERR_LAUNCH, "vit_backward: memset failed");
       RUN(rovit_layernorm_bwd_rows(ws + L.dxhat, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmc, batch, T, stream));
-      // attention backward reads dO for every query: rows other than CLS carry no gradient (the proj dgrad below writes the CLS rows)
-      ROVIT_CHECK_ARG(hipMemsetAsync(ws + L.dO, 0, (size_t)M * D * sizeof(bf16), sA) == hipSuccess, ROVIT_ERR_LAUNCH,
-                      "vit_backward: memset failed");
+      // (no zero fills, round 4: only the CLS rows of dO and of the mid-block gradient carry gradient; the attention backward and the
+      // qkv dgrad below are told so and treat the other rows as zeros without reading them)
       RUN(rovit_gemm_nt(xmc, D * rs, q + P.wprojT, D, Mr, D, D, nullptr, EPI_BF16, ws + L.dO, D * rs, nullptr, nullptr, 0, nullptr, 0, nullptr,
                         0, stream));
       if (ss && !hand_over(ss, sA, sB)) EVFAIL("event hand-over");
@@ -521,8 +518,8 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
             {(const float*)(ws + L.slab_proj), sc, D, D, nullptr, nullptr, nullptr, bg[B_PROJW], bg[B_PROJB], nullptr, nullptr, nullptr}};
         RUN(rovit_wgrad_reduce_batch(rd, 3, sB));
       }
-      RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, dq, batch, T, H, D / H, 0.125f, stream));
-      RUN(rovit_gemm_ln_bwd(dq, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), nullptr, xmc, xout, stream));
+      RUN(rovit_attention_bwd_rows(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, 1, dq, batch, T, H, D / H, 0.125f, stream));
+      RUN(rovit_gemm_ln_bwd_cls(dq, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), xmc, T, xout, stream));
       // the (full-size) qkv weight gradient of this block goes the way of every other block's: as `pending`, into the next block's
       // merged launch on the weight-gradient stream (or the flush behind the loop) instead of 50 us of serial work here
       pending = i;

@@ -159,9 +159,10 @@ SideStream* side_stream() {
     // stream was observed to land on the caller's queue, which serialises the two "concurrent" chains (8.7 instead
     // of 7.1 ms/step with a process group initialised).  High and low priority measured the same within noise: high.
     int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) {
+    const int prio = ROVIT_KNOB(ROVIT_KNOB_SIDE_PRIORITY, 0);
+    if (prio == 2 || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) {
       if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    } else if (hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+    } else if (hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio == 1 ? least : greatest) != hipSuccess) {
       return nullptr;
     }
   }

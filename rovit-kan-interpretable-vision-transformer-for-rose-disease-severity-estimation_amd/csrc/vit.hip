@@ -544,8 +544,14 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
     }
     if (ss && !hand_over(ss, sA, sB)) EVFAIL("event hand-over");                                                   // E_i
     RUN(issue_merged(i, pending, xin, dp, xmid));
-    RUN(rovit_gemm_nt(xmid, D, q + P.wprojT, D, M, D, D, nullptr, EPI_BF16, ws + L.dO, D, nullptr, nullptr, 0, nullptr, 0, nullptr, 0,
-                      sA));                                                                                        // A3
+    {
+      const int cus = ROVIT_KNOB(ROVIT_KNOB_PROJ_DGRAD_CUS, 256);
+      if (cus != 256) rovit_set_cu_budget(cus);
+      const int rc_a3 = rovit_gemm_nt(xmid, D, q + P.wprojT, D, M, D, D, nullptr, EPI_BF16, ws + L.dO, D, nullptr, nullptr, 0, nullptr, 0, nullptr, 0,
+                                      sA);                                                                         // A3
+      if (cus != 256) rovit_set_cu_budget(256);
+      if (rc_a3 != ROVIT_OK) return rc_a3;
+    }
     RUN(rovit_attention_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, dq, batch, T, H, D / H, 0.125f, sA));       // A4
     // qkv dgrad fused with the backward of norm1
     RUN(rovit_gemm_ln_bwd(dq, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), nullptr, xmid, xout, sA));   // A5

@@ -116,6 +116,51 @@ int rovit_heads_bwd(const float* features, const float* const* params, const flo
                     int accumulate_dfeat, rovit_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Head phase in three launches (round 4): everything RoViTKAN.forward does with the backbone features --
+ * the three heads (models/heads.py:17-22, 38-43, 91-102, gated by the curriculum stage, models/rovit_kan.py:93-116)
+ * AND KANSeverityModule.forward (models/kan.py:138-149) -- as ONE forward launch, and its autograd backward as
+ * two (the per-sample gradient chain down to d_features; then every parameter gradient).  One workgroup owns one
+ * sample for the whole phase; parameters are read in the reference layouts (no prepared copies).
+ *   Limits: embed <= 768 and a multiple of 4; hid <= 256 and a multiple of 4; num_classes <= 8; 1..4 KAN layers
+ *   (kan_layers == 0: no KAN stack, stage < 4) whose widths after the input are <= 64; 8..64 knots per layer.
+ *   Dropout on the hidden layers: masks[h] (B,hid) = scaled keep-mask, or -- masks[h] == NULL and drop_p > 0 -- drawn
+ *   in the kernel (Philox4x32-10 keyed by `seed`, counter (sample * hid + unit, offset); kept units scaled by
+ *   1 / (1 - drop_p)); the backward needs no mask then (a kept unit is one whose stored hidden value is > 0).
+ *   Arrays in this struct are HOST arrays of device pointers; every pointer is a device pointer of fp32 data.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct rovit_head_phase {
+  int batch, embed, hid, num_classes, stage;
+  int kan_layers;
+  int kan_dims[5];
+  int kan_knots[4];
+  int kan_acts[4];                /* ROVIT_ACT_* after each layer */
+  float drop_p;
+  unsigned long long seed, offset;
+  const float* features;          /* (B, embed) */
+  const float* head_params[14];   /* order of rovit_heads_fwd */
+  const float* masks[3];
+  const float* kan_w[4];          /* (in, out, nb) */
+  const float* kan_knots_p[4];
+  const float* kan_lw[4];         /* (out, in) */
+  const float* kan_lb[4];
+  /* forward outputs, kept for the backward */
+  float* hidden;                  /* (3, B, hid) post-ReLU / dropout */
+  float* cls; float* ord; float* mu; float* lv;
+  float* kan_out[4];              /* (B, kan_dims[l+1]) post-activation */
+  /* backward inputs: gradients w.r.t. the outputs (NULL: none); g_kan is the last KAN layer's */
+  const float* g_cls; const float* g_ord; const float* g_mu; const float* g_lv; const float* g_kan;
+  /* backward outputs */
+  float* d_features;              /* (B, embed) or NULL */
+  float* dpre;                    /* (3, B, hid) scratch: gradient w.r.t. the heads' pre-activations */
+  float* kan_gz[4];               /* (B, kan_dims[l+1]) scratch: gradient w.r.t. each layer's pre-activation */
+  float* head_grads[14];          /* mirrors head_params; all NULL with want_param_grads == 0 */
+  float* kan_dw[4]; float* kan_dlw[4]; float* kan_dlb[4];
+  int want_param_grads;
+} rovit_head_phase;
+int rovit_head_phase_fwd(const rovit_head_phase* p, rovit_stream_t stream);
+int rovit_head_phase_bwd(const rovit_head_phase* p, rovit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * DeiT-Tiny backbone (models/backbone.py:23-25 -> timm VisionTransformer.forward).
  * params / grads: HOST arrays of rovit_vit_num_params(depth) device pointers (fp32, timm layouts):
  *   [0] cls_token (192) [1] pos_embed (197,192) [2] patch_embed.proj.weight (192,768) [3] .bias [4] norm.weight

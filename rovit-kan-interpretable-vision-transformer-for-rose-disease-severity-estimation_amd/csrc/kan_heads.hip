@@ -10,66 +10,9 @@
 // The (B, in, num_basis) basis tensor the reference materialises (kan.py:20) never exists here: per
 // (sample, input feature) the kernel keeps the knot interval index and the 4 non-zero cubic values in LDS.
 #include "common.h"
+#include "kan_device.h"
 
 namespace {
-
-constexpr int KAN_MAX_KNOTS = 64;
-
-struct Basis4 {
-  int j;        // knot interval, -1 when every basis value is zero (beyond the truncation / saturated)
-  float v[4];   // value of basis j-m, m = 0..3
-};
-
-// knots: LDS or global pointer to nk fp32 knots (uniform by construction, but the STORED values are used
-// for the interval search and for h, as the reference does: kan.py:24,33-38).
-template <bool DERIV>
-__device__ __forceinline__ Basis4 kan_basis(float xn, const float* knots, int nk, float inv_h0, float* dv) {
-  Basis4 r;
-  const int nb = nk - 4;
-  const float t0 = knots[0], tl = knots[nk - 1];
-  float xc = fminf(fmaxf(xn, t0), tl);                         // kan.py:16
-  int j = (int)floorf((xc - t0) * inv_h0);
-  j = j < 0 ? 0 : (j > nk - 1 ? nk - 1 : j);
-  while (j > 0 && xc < knots[j]) --j;                          // exact search on the stored knots
-  while (j < nk - 1 && xc >= knots[j + 1]) ++j;
-  if (j >= nb) {                                               // truncation: SURVEY.md 0.2
-    r.j = -1; r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.f;
-    if (DERIV) dv[0] = dv[1] = dv[2] = dv[3] = 0.f;
-    return r;
-  }
-  const float tj = knots[j];
-  const float h = knots[j + 1] - tj;
-  const float u = (xc - tj) / h;
-  const float u2 = u * u, u3 = u2 * u, om = 1.f - u;
-  r.j = j;
-  r.v[0] = u3 * (1.f / 6.f);
-  r.v[1] = (-3.f * u3 + 3.f * u2 + 3.f * u + 1.f) * (1.f / 6.f);
-  r.v[2] = (3.f * u3 - 6.f * u2 + 4.f) * (1.f / 6.f);
-  r.v[3] = om * om * om * (1.f / 6.f);
-  if (DERIV) {
-    const float ih = 1.f / h;
-    dv[0] = 0.5f * u2 * ih;
-    dv[1] = (-9.f * u2 + 6.f * u + 3.f) * (1.f / 6.f) * ih;
-    dv[2] = (9.f * u2 - 12.f * u) * (1.f / 6.f) * ih;
-    dv[3] = -0.5f * om * om * ih;
-  }
-#pragma unroll
-  for (int m = 0; m < 4; ++m)
-    if (j - m < 0) { r.v[m] = 0.f; if (DERIV) dv[m] = 0.f; }   // left edge loses terms
-  return r;
-}
-
-__device__ __forceinline__ float act_apply(float z, int act) {
-  if (act == ROVIT_ACT_RELU) return fmaxf(z, 0.f);
-  if (act == ROVIT_ACT_SIGMOID3) return 3.f / (1.f + __expf(-z));
-  return z;
-}
-// d(act)/dz expressed through the post-activation value y
-__device__ __forceinline__ float act_grad(float g, float y, int act) {
-  if (act == ROVIT_ACT_RELU) return y > 0.f ? g : 0.f;
-  if (act == ROVIT_ACT_SIGMOID3) return g * y * (1.f - y * (1.f / 3.f));
-  return g;
-}
 
 // ---------------------------------------------------------------------------------------------
 // forward: one workgroup = TB samples.  Phase 1: per (sample, feature) tanh + grid lookup -> LDS.
@@ -456,18 +399,18 @@ __global__ __launch_bounds__(256) void lin_bwd_dx_batch_kernel(const LinDxBatch 
 }
 
 struct LinDwDesc { const float* g; const float* x; const float* yc; float* dw; float* db; int in_f, out_f; };
-struct LinDwBatch { LinDwDesc d[4]; int first[5]; int n, B; };
+struct LinDwBatch { LinDwDesc d[8]; int first[9]; int n, B; };
 
 // One workgroup = 64 consecutive dW elements x 4 batch slices (wave w sums samples w, w+4, ...), partial sums
 // combined through LDS: the sample loop is a chain of dependent global loads, so its length, not the arithmetic, sets
 // the kernel time (62 us with one thread walking all 256 samples).
-__global__ __launch_bounds__(1024) void lin_bwd_dw_batch_kernel(const LinDwBatch pb) {
+__device__ __forceinline__ void lin_dw_body(const LinDwBatch& pb, int bid) {
   __shared__ float s_w[16][64], s_b[16][64];
   int i = 0;
-  while (i + 1 < pb.n && (int)blockIdx.x >= pb.first[i + 1]) ++i;
+  while (i + 1 < pb.n && bid >= pb.first[i + 1]) ++i;
   const LinDwDesc& d = pb.d[i];
   const int el = threadIdx.x & 63, bs = threadIdx.x >> 6;          // 16 batch slices: 16 samples per thread at batch 256
-  const int e = ((int)blockIdx.x - pb.first[i]) * 64 + el;
+  const int e = (bid - pb.first[i]) * 64 + el;
   const bool live = e < d.out_f * d.in_f;
   const int o = live ? e / d.in_f : 0, k = live ? e - o * d.in_f : 0;
   float acc = 0.f, accb = 0.f;
@@ -488,6 +431,7 @@ __global__ __launch_bounds__(1024) void lin_bwd_dw_batch_kernel(const LinDwBatch
     if (k == 0) d.db[o] = tb;
   }
 }
+__global__ __launch_bounds__(1024) void lin_bwd_dw_batch_kernel(const LinDwBatch pb) { lin_dw_body(pb, (int)blockIdx.x); }
 
 template <class Batch, class Kernel>
 int launch_lin_batch(Batch& pb, int n, const int* work, Kernel kern, const char* name, hipStream_t st, int per_block = 256, int threads = 256) {
@@ -608,12 +552,11 @@ __global__ __launch_bounds__(1024) void kan_stack_bwd_dx_kernel(const KanStackBw
 }
 
 // parameter gradients of every layer: workgroup -> (layer, input feature i); owns dW[i,:,:], dlin_w[:,i] (and dlin_b for i = 0)
-__global__ __launch_bounds__(1024) void kan_stack_bwd_dw_kernel(const KanStackBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void kan_dw_body(const KanStackBwdArgs& a, const int bid, float* smem) {
   int l = 0;
 #pragma unroll
   for (int q = 1; q < KB_MAX_LAYERS; ++q)
-    if (q < a.nl && (int)blockIdx.x >= a.wg0[q]) l = q;
+    if (q < a.nl && bid >= a.wg0[q]) l = q;
   // (scalar copies of the selected layer: l is workgroup-uniform)
   int in_f = a.dims[0], out_f = a.dims[1], nk = a.nk[0], BC = a.bc[0], wg0 = a.wg0[0], T = a.thr[0];
   const float *x = a.x, *knots = a.knots[0], *gzp = a.gz[0];
@@ -635,7 +578,7 @@ __global__ __launch_bounds__(1024) void kan_stack_bwd_dw_kernel(const KanStackBw
   const int tid = threadIdx.x;
   const bool on = tid < T;
   const int nb = nk - 4;
-  const int i = (int)blockIdx.x - wg0;
+  const int i = bid - wg0;
   if (tid < nk) s_knots[tid] = knots[tid];
   __syncthreads();
   const float inv_h0 = 1.f / (s_knots[1] - s_knots[0]);
@@ -715,6 +658,19 @@ __global__ __launch_bounds__(1024) void kan_stack_bwd_dw_kernel(const KanStackBw
       }
     }
   }
+}
+
+__global__ __launch_bounds__(1024) void kan_stack_bwd_dw_kernel(const KanStackBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  kan_dw_body(a, (int)blockIdx.x, smem);
+}
+
+// every parameter gradient of the head phase in ONE grid (head_phase.hip): workgroups [0, kan_wgs) are the (layer, input feature)
+// workgroups of the KAN stack, the rest the 64-element slices of the head linears' weight gradients
+__global__ __launch_bounds__(1024) void head_phase_dw_kernel(const KanStackBwdArgs a, const LinDwBatch pb, int kan_wgs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < kan_wgs) kan_dw_body(a, (int)blockIdx.x, smem);
+  else lin_dw_body(pb, (int)blockIdx.x - kan_wgs);
 }
 
 int kan_tb(int out_f) { int tb = 64 / (out_f > 0 ? out_f : 1); return tb < 1 ? 1 : (tb > 16 ? 16 : tb); }
@@ -957,4 +913,67 @@ extern "C" int rovit_heads_bwd(const float* features, const float* const* params
   rc = launch_lin_batch(dxf, 1, wf, lin_bwd_dx_batch_kernel, "lin_bwd_dx_batch_kernel", st);
   if (rc) return rc;
   return launch_lin_batch(dw1, n1, w1, lin_bwd_dw_batch_kernel, "lin_bwd_dw_batch_kernel", st, 64, 1024);
+}
+
+// Parameter gradients of the whole head phase (head_phase.hip) in one launch.  Not part of the C ABI: called by
+// rovit_head_phase_bwd behind its per-sample kernel, which has written dpre (heads) and gz (KAN layers).
+int rovit_head_phase_dw_launch(const rovit_head_phase* p, hipStream_t st) {
+  const int B = p->batch, E = p->embed, hid = p->hid, C = p->num_classes;
+  const size_t hs = (size_t)B * hid;
+  KanStackBwdArgs a{};
+  int kan_wgs = 0;
+  size_t lds = 0;
+  if (p->kan_layers > 0 && p->g_kan) {
+    a.x = p->features; a.B = B; a.nl = p->kan_layers; a.dx = nullptr;
+    for (int l = 0; l <= p->kan_layers; ++l) a.dims[l] = p->kan_dims[l];
+    for (int l = 0; l < p->kan_layers; ++l) {
+      ROVIT_CHECK_ARG(p->kan_dw[l] && p->kan_dlw[l] && p->kan_dlb[l] && p->kan_gz[l], ROVIT_ERR_NULL,
+                      "head_phase_bwd: parameter-gradient buffers of KAN layer %d missing", l);
+      a.W[l] = p->kan_w[l]; a.knots[l] = p->kan_knots_p[l]; a.lw[l] = p->kan_lw[l]; a.y[l] = p->kan_out[l]; a.gy[l] = nullptr; a.gz[l] = p->kan_gz[l];
+      a.nk[l] = p->kan_knots[l]; a.act[l] = p->kan_acts[l];
+      a.dW[l] = p->kan_dw[l]; a.dlw[l] = p->kan_dlw[l]; a.dlb[l] = p->kan_dlb[l];
+      const int nb = p->kan_knots[l] - 4;
+      int bc = (24 * 1024) / (nb + 1 + p->kan_dims[l + 1]);
+      bc = bc > B ? B : bc;
+      a.bc[l] = bc;
+      a.thr[l] = p->kan_dims[l + 1] * (nb + 2) >= 512 ? 1024 : 256;
+      const size_t need = (KAN_MAX_KNOTS + (size_t)bc * (nb + 1 + p->kan_dims[l + 1]) + 1024) * sizeof(float);
+      lds = need > lds ? need : lds;
+      a.wg0[l] = kan_wgs;
+      kan_wgs += p->kan_dims[l];
+    }
+    a.wg0[p->kan_layers] = kan_wgs;
+  }
+  LinDwBatch pb{};
+  pb.B = B;
+  int n = 0, blocks = 0;
+  auto add = [&](const float* g, const float* x, const float* yc, float* dw, float* db, int in_f, int out_f) -> bool {
+    if (!dw || !db) return false;
+    pb.d[n] = {g, x, yc, dw, db, in_f, out_f};
+    pb.first[n++] = blocks;
+    blocks += (in_f * out_f + 63) / 64;
+    return true;
+  };
+  const float* g_out[3] = {p->g_cls, p->g_ord, p->g_mu};
+  const int nheads = p->stage >= 3 ? 3 : (p->stage >= 2 ? 2 : 1);
+  for (int h = 0; h < nheads; ++h) {
+    if (!g_out[h]) continue;
+    ROVIT_CHECK_ARG(add(p->dpre + h * hs, p->features, nullptr, p->head_grads[4 * h], p->head_grads[4 * h + 1], E, hid), ROVIT_ERR_NULL,
+                    "head_phase_bwd: fc1 gradient buffers of head %d missing", h);
+    bool ok;
+    if (h == 0) ok = add(p->g_cls, p->hidden, nullptr, p->head_grads[2], p->head_grads[3], hid, C);
+    else if (h == 1) ok = add(p->g_ord, p->hidden + hs, nullptr, p->head_grads[6], p->head_grads[7], hid, C - 1);
+    else ok = add(p->g_mu, p->hidden + 2 * hs, nullptr, p->head_grads[10], p->head_grads[11], hid, 1) &&
+              add(p->g_lv, p->hidden + 2 * hs, p->lv, p->head_grads[12], p->head_grads[13], hid, 1);
+    ROVIT_CHECK_ARG(ok, ROVIT_ERR_NULL, "head_phase_bwd: output-linear gradient buffers of head %d missing", h);
+  }
+  pb.first[n] = blocks;
+  pb.n = n;
+  if (kan_wgs + blocks == 0) return ROVIT_OK;
+  ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)head_phase_dw_kernel, (size_t)(104 * 1024)), ROVIT_ERR_LAUNCH,
+                  "head_phase_bwd: cannot raise the LDS limit");
+  ROVIT_CHECK_ARG(lds <= 104 * 1024, ROVIT_ERR_SHAPE, "head_phase_bwd: the KAN weight-gradient tile needs %zu bytes of LDS", lds);
+  hipLaunchKernelGGL(head_phase_dw_kernel, dim3(kan_wgs + blocks), dim3(1024), lds, st, a, pb, kan_wgs);
+  ROVIT_CHECK_LAUNCH("head_phase_dw_kernel");
+  return ROVIT_OK;
 }

@@ -6,7 +6,7 @@ from typing import Dict
 import torch
 import torch.nn as nn
 
-from rovit_hip.functions import HeadsFn
+from rovit_hip.functions import ACT_RELU, ACT_SIGMOID3, HeadPhaseFn, HeadsFn
 
 from .backbone import DeiTTinyBackbone
 from .heads import ClassificationHead, OrdinalHead, UncertaintyHead, dropout_mask
@@ -56,6 +56,8 @@ class RoViTKAN(nn.Module):
         if x.shape[0] == 0:
             return self._empty_outputs(x, stage)
         features = self.backbone(x)
+        if self._head_phase_fusable(features):
+            return self._forward_head_phase(features, stage)
         B, hid = features.shape[0], self.classification_head.fc1.out_features
         masks = None
         if self.training:
@@ -77,6 +79,67 @@ class RoViTKAN(nn.Module):
             'mu': mu if stage >= 3 else None,
             'log_var': log_var if stage >= 3 else None,
             'kan_severity': self.kan_module(features) if stage >= 4 else None,
+        }
+
+    # ---- the head phase as one forward launch and a two-launch backward (csrc/head_phase.hip) ----------------------------
+    head_phase_max_batch = 1024        # one workgroup per sample: beyond this the per-module kernels (sample tiles, matrix cores) win
+
+    def _head_phase_fusable(self, features: torch.Tensor) -> bool:
+        """Shapes the fused kernels cover, and nothing a caller could observe differently: a forward / backward hook on any
+        head or KAN sub-module would not fire from inside the fused launch, so such a model takes the per-module path."""
+        if not features.is_cuda or features.dim() != 2 or not (0 < features.shape[0] <= self.head_phase_max_batch):
+            return False
+        c, o, u, k = self.classification_head, self.ordinal_head, self.uncertainty_head, self.kan_module
+        if not (type(c) is ClassificationHead and type(o) is OrdinalHead and type(u) is UncertaintyHead and type(k) is KANSeverityModule):
+            return False
+        E, hid, C = features.shape[1], c.fc1.out_features, c.fc2.out_features
+        if not (c.fc1.in_features == o.fc1.in_features == u.fc1.in_features == E and o.fc1.out_features == hid == u.fc1.out_features):
+            return False
+        if not (E % 4 == 0 and E <= 768 and hid % 4 == 0 and hid <= 256 and 2 <= C <= 8 and o.fc2.out_features == C - 1):
+            return False
+        d = k.layers_dims
+        if not (k.degree == 3 and 1 <= len(k.kan_layers) <= 4 and d[0] == E and all(1 <= w <= 64 for w in d[1:]) and
+                all(8 <= l.knots.numel() <= 64 for l in k.kan_layers)):
+            return False
+        if self.training and len({h.dropout.p for h in (c, o, u)}) != 1:
+            return False
+        for top in (c, o, u, k):
+            for m in top.modules():
+                if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, '_backward_pre_hooks', None):
+                    return False
+        return True
+
+    def _kan_params(self):
+        out = []
+        for l in self.kan_module.kan_layers:
+            out += [l.spline_weights, l.linear.weight, l.linear.bias]
+        return out
+
+    def _forward_head_phase(self, features: torch.Tensor, stage: int) -> Dict[str, torch.Tensor]:
+        k = self.kan_module
+        nl = len(k.kan_layers)
+        cfg = {'stage': stage, 'masks': None, 'drop_p': 0.0, 'seed': 0, 'offset': 0,
+               'kan_dims': list(k.layers_dims) if stage >= 4 else [],
+               'kan_knots': [l.knots for l in k.kan_layers] if stage >= 4 else [],
+               'kan_acts': [ACT_SIGMOID3 if i == nl - 1 else ACT_RELU for i in range(nl)],
+               'grad_views': getattr(self, '_head_grad_views', None)}
+        p = self.classification_head.dropout.p
+        if self.training and p > 0.0:
+            # dropout drawn inside the kernel (Philox keyed by the device generator's seed, counter advanced like torch's own kernels do)
+            gen = torch.cuda.default_generators[features.device.index]
+            n = features.shape[0] * self.classification_head.fc1.out_features
+            off = gen.get_offset()
+            gen.set_offset(off + 4 * ((n + 3) // 4))
+            cfg.update(drop_p=float(p), seed=gen.initial_seed(), offset=off)
+        cls_logits, ordinal_logits, mu, log_var, kan = HeadPhaseFn.apply(features, cfg, *self._head_params(),
+                                                                         *(self._kan_params() if stage >= 4 else []))
+        return {
+            'cls_logits': cls_logits,
+            'features': features,
+            'ordinal_logits': ordinal_logits if stage >= 2 else None,
+            'mu': mu if stage >= 3 else None,
+            'log_var': log_var if stage >= 3 else None,
+            'kan_severity': kan if stage >= 4 else None,
         }
 
     def _empty_outputs(self, x: torch.Tensor, stage: int) -> Dict[str, torch.Tensor]:

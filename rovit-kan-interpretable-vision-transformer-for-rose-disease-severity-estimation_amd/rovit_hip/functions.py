@@ -188,6 +188,143 @@ class HeadsFn(torch.autograd.Function):
         return (dfeat, None, None, *grads)
 
 
+class HeadPhaseFn(torch.autograd.Function):
+    """Everything RoViTKAN.forward does with the features (reference models/rovit_kan.py:93-124) as ONE forward launch and a
+    two-launch backward (rovit_head_phase_fwd / _bwd, csrc/head_phase.hip): the three heads and the KAN stack.
+
+    inputs: features, cfg, the 14 head parameters (order of rovit_heads_fwd), then (spline_w, lin_w, lin_b) per KAN layer.
+    cfg: stage; masks (list of 3 scaled keep-masks / None entries) or None; drop_p, seed, offset (dropout drawn in the kernel
+    when masks is None and drop_p > 0); kan_knots (list of knot buffers), kan_acts, kan_dims ([] = no KAN stack);
+    grad_views: optional {param.data_ptr(): tensor} of flat-buffer views the parameter gradients may be written into directly.
+    outputs: cls, ord, mu, log_var, kan (the last KAN layer's output); inactive ones are zero-size placeholders."""
+
+    @staticmethod
+    def _desc(features, cfg, head_params, kan_params):
+        import ctypes as C
+        d = native.HeadPhase()
+        B, E = features.shape
+        d.batch, d.embed, d.hid, d.num_classes, d.stage = B, E, head_params[0].shape[0], head_params[2].shape[0], cfg['stage']
+        dims = cfg['kan_dims']
+        nl = len(dims) - 1 if dims else 0
+        d.kan_layers = nl
+        for l in range(nl + 1 if nl else 0):
+            d.kan_dims[l] = dims[l]
+        for l in range(nl):
+            d.kan_knots[l] = cfg['kan_knots'][l].numel()
+            d.kan_acts[l] = cfg['kan_acts'][l]
+            d.kan_w[l], d.kan_lw[l], d.kan_lb[l] = (ptr(kan_params[3 * l + q]) for q in range(3))
+            d.kan_knots_p[l] = ptr(cfg['kan_knots'][l])
+        d.drop_p, d.seed, d.offset = float(cfg.get('drop_p', 0.0)), int(cfg.get('seed', 0)), int(cfg.get('offset', 0))
+        d.features = ptr(features)
+        for i, p_ in enumerate(head_params):
+            d.head_params[i] = ptr(p_)
+        masks = cfg.get('masks')
+        if masks is not None:
+            for h, m in enumerate(masks):
+                d.masks[h] = ptr(m) if m is not None else None
+        return d
+
+    @staticmethod
+    def forward(ctx, features, cfg, *params):
+        features = _f32c(features)
+        ptr(features)                              # a CPU tensor is refused here (RovitHipError)
+        params = [_f32c(p) for p in params]
+        head_params, kan_params = params[:14], params[14:]
+        if cfg.get('masks') is not None:
+            cfg = dict(cfg, masks=[_f32c(m) if m is not None else None for m in cfg['masks']])
+        B = features.shape[0]
+        dev = features.device
+        hid, C_ = head_params[0].shape[0], head_params[2].shape[0]
+        stage = cfg['stage']
+        dims = cfg['kan_dims']
+        nl = len(dims) - 1 if dims else 0
+        d = HeadPhaseFn._desc(features, cfg, head_params, kan_params)
+        hidden = torch.empty(3, B, hid, device=dev, dtype=torch.float32)
+        cls = torch.empty(B, C_, device=dev, dtype=torch.float32)
+        empty = cls.new_empty(0)
+        ordl = torch.empty(B, C_ - 1, device=dev, dtype=torch.float32) if stage >= 2 else empty
+        mu = torch.empty(B, 1, device=dev, dtype=torch.float32) if stage >= 3 else empty
+        lv = torch.empty(B, 1, device=dev, dtype=torch.float32) if stage >= 3 else empty
+        kouts = [torch.empty(B, dims[l + 1], device=dev, dtype=torch.float32) for l in range(nl)]
+        d.hidden, d.cls = ptr(hidden), ptr(cls)
+        d.ord, d.mu, d.lv = (ptr(t) if t.numel() else None for t in (ordl, mu, lv))
+        for l in range(nl):
+            d.kan_out[l] = ptr(kouts[l])
+        import ctypes as C
+        call('rovit_head_phase_fwd', C.byref(d), stream_ptr())
+        ctx.save_for_backward(features, hidden, lv, *params, *kouts)
+        ctx.cfg, ctx.nl = cfg, nl
+        kan = kouts[-1] if nl else empty
+        outs = (cls, ordl, mu, lv, kan)
+        ctx.mark_non_differentiable(*[o for o in outs if o.numel() == 0])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_cls, g_ord, g_mu, g_lv, g_kan):
+        import ctypes as C
+        saved = ctx.saved_tensors
+        nl, cfg = ctx.nl, ctx.cfg
+        features, hidden, lv = saved[:3]
+        params = saved[3:3 + 14 + 3 * nl]
+        kouts = saved[3 + 14 + 3 * nl:]
+        head_params, kan_params = params[:14], params[14:]
+        B, E = features.shape
+        hid = head_params[0].shape[0]
+        stage = cfg['stage']
+        dev = features.device
+
+        def act(g, active):
+            return _f32c(g) if (active and g is not None) else None
+        g_cls, g_ord = act(g_cls, True), act(g_ord, stage >= 2)
+        g_mu, g_lv = act(g_mu, stage >= 3), act(g_lv, stage >= 3)
+        g_kan = act(g_kan, nl > 0)
+        if (g_mu is None) != (g_lv is None):          # one of the pair unused by the loss: treat as zero
+            z = torch.zeros(B, 1, device=dev, dtype=torch.float32)
+            g_mu = g_mu if g_mu is not None else z
+            g_lv = g_lv if g_lv is not None else z
+        d = HeadPhaseFn._desc(features, cfg, head_params, kan_params)
+        d.hidden = ptr(hidden)
+        d.lv = ptr(lv) if lv.numel() else None
+        for l in range(nl):
+            d.kan_out[l] = ptr(kouts[l])
+        d.g_cls, d.g_ord, d.g_mu, d.g_lv, d.g_kan = ptr(g_cls), ptr(g_ord), ptr(g_mu), ptr(g_lv), ptr(g_kan)
+        need_dx = ctx.needs_input_grad[0]
+        dfeat = torch.empty_like(features) if need_dx else None
+        d.d_features = ptr(dfeat)
+        dims = cfg['kan_dims']
+        scratch = torch.empty(3 * B * hid + B * sum(dims[1:]) if nl else 3 * B * hid, device=dev, dtype=torch.float32)
+        d.dpre = ptr(scratch)
+        off = 3 * B * hid
+        keep = [scratch]
+        for l in range(nl):
+            d.kan_gz[l] = scratch.data_ptr() + 4 * off
+            off += B * dims[l + 1]
+        # parameter gradients: written straight into the optimizer's flat gradient buffer when it offered views and nothing has been
+        # accumulated yet (autograd then installs the view as .grad without a copy); otherwise into fresh tensors
+        live_h = [g_cls is not None] * 4 + [g_ord is not None] * 4 + [g_mu is not None] * 6
+        live_k = [g_kan is not None] * (3 * nl)
+        need = [ctx.needs_input_grad[2 + i] for i in range(14 + 3 * nl)]
+        want = any(n and l for n, l in zip(need, live_h + live_k))
+        views = cfg.get('grad_views')
+        direct = bool(views) and all(p_.grad is None for p_ in params)
+        grads = [None] * (14 + 3 * nl)
+        if want:
+            for i, (p_, l) in enumerate(zip(params, live_h + live_k)):
+                if not l:
+                    continue
+                v = views.get(p_.data_ptr()) if direct else None
+                grads[i] = v.view_as(p_) if v is not None else torch.empty_like(p_)      # a FRESH alias: see AccumulateGrad's stealing rule
+            for i in range(14):
+                d.head_grads[i] = ptr(grads[i])
+            for l in range(nl):
+                d.kan_dw[l], d.kan_dlw[l], d.kan_dlb[l] = (ptr(grads[14 + 3 * l + q]) for q in range(3))
+        d.want_param_grads = int(want)
+        call('rovit_head_phase_bwd', C.byref(d), stream_ptr())
+        del keep
+        out = [g if n else None for g, n in zip(grads, need)]
+        return (dfeat, None, *out)
+
+
 class MLPHeadFn(torch.autograd.Function):
     """One stand-alone head: Linear -> ReLU -> dropout mask -> one or more output Linears
     (models/heads.py:17-22, 38-43, 91-102).  inputs: x, mask|None, flags-per-output, w1, b1, (w, b)*."""

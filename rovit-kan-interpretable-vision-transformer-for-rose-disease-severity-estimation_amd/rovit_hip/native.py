@@ -41,6 +41,8 @@ SIGNATURES = {
     'rovit_linear_bwd': (_i, [_vp] * 9 + [_i] * 4 + [_vp]),
     'rovit_heads_fwd': (_i, [_vp] * 8 + [_i] * 5 + [_vp]),
     'rovit_heads_bwd': (_i, [_vp] * 12 + [_i] * 5 + [_vp]),
+    'rovit_head_phase_fwd': (_i, [_vp, _vp]),
+    'rovit_head_phase_bwd': (_i, [_vp, _vp]),
     'rovit_vit_num_params': (_i, [_i]),
     'rovit_vit_prep_bytes': (_sz, [_i]),
     'rovit_vit_workspace_bytes': (_sz, [_i, _i, _i]),
@@ -87,6 +89,19 @@ SIGNATURES = {
     'rovit_clip_coef': (_i, [_vp, _f, _vp, _vp, _vp]),
     'rovit_adamw_flat': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _i, _vp]),
 }
+
+
+class HeadPhase(C.Structure):
+    """``rovit_head_phase`` of include/rovit_hip.h, field for field (HOST arrays of device pointers inside)."""
+    _fields_ = [('batch', _i), ('embed', _i), ('hid', _i), ('num_classes', _i), ('stage', _i), ('kan_layers', _i),
+                ('kan_dims', _i * 5), ('kan_knots', _i * 4), ('kan_acts', _i * 4), ('drop_p', _f),
+                ('seed', C.c_ulonglong), ('offset', C.c_ulonglong),
+                ('features', _vp), ('head_params', _vp * 14), ('masks', _vp * 3), ('kan_w', _vp * 4), ('kan_knots_p', _vp * 4),
+                ('kan_lw', _vp * 4), ('kan_lb', _vp * 4),
+                ('hidden', _vp), ('cls', _vp), ('ord', _vp), ('mu', _vp), ('lv', _vp), ('kan_out', _vp * 4),
+                ('g_cls', _vp), ('g_ord', _vp), ('g_mu', _vp), ('g_lv', _vp), ('g_kan', _vp),
+                ('d_features', _vp), ('dpre', _vp), ('kan_gz', _vp * 4), ('head_grads', _vp * 14), ('kan_dw', _vp * 4),
+                ('kan_dlw', _vp * 4), ('kan_dlb', _vp * 4), ('want_param_grads', _i)]
 
 
 # entry points only the developer library exports (round-2 / round-3 experiments that lost; tools/ A/B them)

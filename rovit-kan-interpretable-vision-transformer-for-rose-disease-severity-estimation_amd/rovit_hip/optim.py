@@ -110,6 +110,8 @@ class RoViTAdamW(torch.optim.Optimizer):
             s.grad_views = [self.o_grad[o:o + p.numel()].view_as(p) for o, p in zip(s.offsets, s.params)]
         self.o_m = torch.zeros_like(self.o_flat)
         self.o_v = torch.zeros_like(self.o_flat)
+        # the fused head phase (models/rovit_kan.py) may write its parameter gradients straight into these views: no per-step pack copy
+        self.model._head_grad_views = {p.data_ptr(): v for s in self.segments for p, v in zip(s.params, s.grad_views)}
         if old is not None:                                  # the model was moved after the buffers existed: keep the moments
             for dst, src in zip((self.m_flat, self.v_flat, self.o_m, self.o_v), old):
                 dst.copy_(src)

@@ -159,6 +159,8 @@ typedef struct rovit_head_phase {
 } rovit_head_phase;
 int rovit_head_phase_fwd(const rovit_head_phase* p, rovit_stream_t stream);
 int rovit_head_phase_bwd(const rovit_head_phase* p, rovit_stream_t stream);
+/* the parameter-gradient launch of rovit_head_phase_bwd alone (after a want_param_grads == 0 call; e.g. on another stream) */
+int rovit_head_phase_bwd_params(const rovit_head_phase* p, rovit_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * DeiT-Tiny backbone (models/backbone.py:23-25 -> timm VisionTransformer.forward).
@@ -182,6 +184,11 @@ int rovit_vit_prepare(const float* const* params, void* prep, int depth, rovit_s
 enum { ROVIT_MLP_AUTO = 0, ROVIT_MLP_TWO_LAUNCH = 1, ROVIT_MLP_ONE_LAUNCH = 2 };
 int rovit_vit_forward(const float* images, const float* const* params, const void* prep, void* workspace, float* features,
                       int batch, int depth, int training, int mlp_path, rovit_stream_t stream);
+/* rovit_vit_prepare + rovit_vit_forward in one call (every training step re-prepares the weights): the per-block weight images are
+ * written on the library's second stream beside the patch embedding, not in front of the forward (41 us per step at depth 12).
+ * write_tables != 0 also writes prep's constant look-up tables: needed the first time a prep buffer is used. */
+int rovit_vit_forward_prepare(const float* images, const float* const* params, void* prep, void* workspace, float* features, int batch,
+                              int depth, int training, int mlp_path, int write_tables, rovit_stream_t stream);
 /* forward + explainability taps: attn_taps is a HOST array of `depth` device pointers (bf16 (B*197,192)) that receive
  * each block's attention-module output -- what DeiTTinyBackbone.get_attention_maps collects through forward hooks on
  * `blocks[i].attn` (models/backbone.py:37-62).  prob_taps (optional, like attn_taps): fp32 (B,3,197,197) softmax
@@ -348,18 +355,27 @@ int rovit_sq_norm_accum(const float* g, size_t n, float* out_sq, float* scratch,
 int rovit_clip_coef(const float* sq, float max_norm, float* coef, float* norm_out, rovit_stream_t stream);
 int rovit_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, const float* grad_scale, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int t, rovit_stream_t stream);
+/* The same two steps as ONE launch each (round 4).  rovit_sq_norm_clip: squared norm over up to four buffers (HOST arrays bufs /
+ * counts; 16-byte aligned, counts multiples of 4), block partials added in block order by the block that finishes last, then the
+ * coefficient; scratch >= 264 floats, zeroed ONCE by the caller (the kernel re-arms its ticket).
+ * rovit_adamw_flat_multi: rovit_adamw_flat over up to four segments with their own lr and step count t (HOST arrays). */
+int rovit_sq_norm_clip(const float* const* bufs, const size_t* counts, int n_bufs, float max_norm, float* coef, float* norm_out,
+                       float* scratch, size_t scratch_floats, rovit_stream_t stream);
+int rovit_adamw_flat_multi(float* const* p, const float* const* g, float* const* m, float* const* v, const size_t* n, const float* lr,
+                           const int* t, int n_segs, const float* grad_scale, float beta1, float beta2, float eps, float weight_decay,
+                           rovit_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Joint multi-task loss, forward + gradient in one launch: JointLoss.forward (training/losses.py:139-181) with
  * FocalLoss (:15-38), OrdinalBCELoss (:48-72), UncertaintyLoss (:80-101), KANRegressionLoss (:109-114).
- * Class targets are int64 (torch.long), severity targets fp32 (the reference casts them with .float(), :89-90,
- * :110-111; ordinal targets are (severity > k), :55-56).  A class label outside [0, num_classes) makes every loss NaN
+ * Class targets are int64 (torch.long); severity targets fp32, or int64 labels with severity_is_int64 != 0 (the reference casts
+ * them with .float(), :89-90, :110-111 -- done inside the kernel; ordinal targets are (severity > k), :55-56).  A class label outside [0, num_classes) makes every loss NaN
  * instead of reading out of bounds.  NULL head pointers = head inactive at this curriculum stage.
  * d_* = d(total)/d(head output) for an upstream gradient of 1; losses_out = [cls, ord, unc, kan, total].
  * rovit_scale_buffers multiplies up to 5 buffers by a device scalar (chain rule with the upstream gradient).
  * ------------------------------------------------------------------------------------------------------------ */
 int rovit_joint_loss(const float* cls_logits, const float* ordinal_logits, const float* mu, const float* log_var,
-                     const float* kan_severity, const long long* class_targets, const float* severity_targets,
+                     const float* kan_severity, const long long* class_targets, const void* severity_targets, int severity_is_int64,
                      const float* focal_alpha, float* d_cls, float* d_ord, float* d_mu, float* d_lv, float* d_kan,
                      float* losses_out, int batch, int num_classes, float lambda_ord, float mu_unc, float nu_kan, float focal_gamma,
                      rovit_stream_t stream);

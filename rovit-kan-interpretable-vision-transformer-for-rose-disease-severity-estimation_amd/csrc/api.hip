@@ -15,7 +15,8 @@ void rovit_set_error(const char* fmt, ...) {
 // 100: round 1.  200: round 2 changed rovit_vit_backward(_notify) (leading `images`) and rovit_joint_loss (float severity targets).
 // 300: round 3 adds the fused MLP entry points and the prepared-weight stream they read (rovit_vit_prep_bytes grew).
 // 400: round 4 -- rovit_vit_forward / _backward(_notify) take `mlp_path`; every rovit_set_* knob and the experiments that lost left the ABI.
-extern "C" int rovit_version(void) { return 400; }
+// 410: round 4 -- rovit_joint_loss takes int64 severity labels (severity_is_int64); rovit_head_phase_*, rovit_sq_norm_clip, rovit_adamw_flat_multi added.
+extern "C" int rovit_version(void) { return 410; }
 extern "C" const char* rovit_last_error_string(void) { return g_err; }
 
 #include <mutex>

@@ -222,6 +222,6 @@ struct RovitReduceDesc {
 };
 // mlp_fused.hip: weight streams of `depth` blocks laid out inside the prepared-weight buffer (byte offsets)
 int rovit_mlp_stream_prep_blocks(const void* prep_base, size_t blk0, size_t stride, size_t off_w1, size_t off_w2, size_t off_out,
-                                 size_t off_wp, int bwd, size_t off_wq_next, int depth, rovit_stream_t stream);
+                                 size_t off_wp, int bwd, size_t off_wq_next, int depth, rovit_stream_t stream, bool gelu_tables = true);
 constexpr int ROVIT_REDUCE_BATCH = 4;
 int rovit_wgrad_reduce_batch(const RovitReduceDesc* descs, int n, rovit_stream_t stream);

@@ -180,9 +180,13 @@ __global__ __launch_bounds__(HP_NT) void head_phase_fwd_kernel(const rovit_head_
 
   // (B) spline term of KAN layer 0: thread = (output o, feature slice); partial sums meet in LDS
   if (kan) {
+    // Every workgroup reads the SAME weights: walking them in the same order at the same time would send all CUs of an XCD to one L2
+    // channel at a time.  Workgroup b starts `b` slices (rows, below) further on; the partial sums keep their slice index, so the order
+    // of the final sums -- and the result -- does not depend on the rotation.
     const int S = HP_NT / out0, fps = (E + S - 1) / S;
-    const int sl = tid / out0, o = tid - sl * out0;
-    if (sl < S) {
+    const int sl0 = tid / out0, o = tid - sl0 * out0;
+    if (sl0 < S) {
+      const int sl = (sl0 + b) % S;
       const int nb = p.kan_knots[0] - 4;
       const int i0 = sl * fps, i1 = min(E, i0 + fps);
       const float* W = p.kan_w[0] + (size_t)o * nb;
@@ -196,8 +200,11 @@ __global__ __launch_bounds__(HP_NT) void head_phase_fwd_kernel(const rovit_head_
   {
     const int R = nheads * hid + out0, E4 = E / 4;
     const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+    const int rot = (b * 29) % R;
     for (int item = tid; item < R * 4; item += HP_NT) {
-      const int r = item >> 2, part = item & 3;
+      const int part = item & 3;
+      int r = (item >> 2) + rot;
+      r = r >= R ? r - R : r;
       const float4* wrow = (const float4*)hp_dense_row(p, r, hid, nheads, E);
       float acc = 0.f;
 #pragma unroll 6
@@ -376,8 +383,11 @@ __global__ __launch_bounds__(HP_NT) void head_phase_bwd_dx_kernel(const rovit_he
   if (kan) {
     const int nb = p.kan_knots[0] - 4;
     const float* W = p.kan_w[0];
+    const int roti = (b * 7) % E;
     for (int item = tid; item < E * 16; item += HP_NT) {
-      const int i = item >> 4, part = item & 15;
+      const int part = item & 15;
+      int i = (item >> 4) + roti;
+      i = i >= E ? i - E : i;
       float acc = 0.f;
 #pragma unroll 4
       for (int o = part; o < out0; o += 16) acc = fmaf(s.lin[o], hp_dot_basis<NBC>(s.bas + 8 * i, W + ((size_t)i * out0 + o) * nb), acc);
@@ -389,8 +399,9 @@ __global__ __launch_bounds__(HP_NT) void head_phase_bwd_dx_kernel(const rovit_he
   const int R = nheads * hid + out0, E4 = E / 4;
   const int S2 = HP_NT / E4, rps = (R + S2 - 1) / S2;
   {
-    const int sl = tid / E4, c = tid - sl * E4;
-    if (sl < S2) {
+    const int sl0 = tid / E4, c = tid - sl0 * E4;
+    const int sl = (sl0 + b) % S2;
+    if (sl0 < S2) {
       const int r0 = sl * rps, r1 = min(R, r0 + rps);
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
@@ -489,4 +500,13 @@ extern "C" int rovit_head_phase_bwd(const rovit_head_phase* p, rovit_stream_t st
   ROVIT_CHECK_LAUNCH("head_phase_bwd_dx_kernel");
   if (p->want_param_grads) return rovit_head_phase_dw_launch(p, (hipStream_t)stream);
   return ROVIT_OK;
+}
+
+// The parameter-gradient launch alone (a caller that ran rovit_head_phase_bwd with want_param_grads == 0 on one stream and wants the
+// sample sums on another, beside the backbone's backward: they are not on the path to d_features).
+extern "C" int rovit_head_phase_bwd_params(const rovit_head_phase* p, rovit_stream_t stream) {
+  const int rc = hp_check(p, "head_phase_bwd_params");
+  if (rc) return rc;
+  ROVIT_CHECK_ARG(p->dpre, ROVIT_ERR_NULL, "head_phase_bwd_params: dpre (written by rovit_head_phase_bwd) missing");
+  return rovit_head_phase_dw_launch(p, (hipStream_t)stream);
 }

@@ -404,7 +404,7 @@ struct LinDwBatch { LinDwDesc d[8]; int first[9]; int n, B; };
 // One workgroup = 64 consecutive dW elements x 4 batch slices (wave w sums samples w, w+4, ...), partial sums
 // combined through LDS: the sample loop is a chain of dependent global loads, so its length, not the arithmetic, sets
 // the kernel time (62 us with one thread walking all 256 samples).
-__device__ __forceinline__ void lin_dw_body(const LinDwBatch& pb, int bid) {
+__device__ __forceinline__ void lin_dw_body(const LinDwBatch pb, int bid) {
   __shared__ float s_w[16][64], s_b[16][64];
   int i = 0;
   while (i + 1 < pb.n && bid >= pb.first[i + 1]) ++i;
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(1024) void kan_stack_bwd_dx_kernel(const KanStackBw
 }
 
 // parameter gradients of every layer: workgroup -> (layer, input feature i); owns dW[i,:,:], dlin_w[:,i] (and dlin_b for i = 0)
-__device__ __forceinline__ void kan_dw_body(const KanStackBwdArgs& a, const int bid, float* smem) {
+__device__ __forceinline__ void kan_dw_body(const KanStackBwdArgs a, const int bid, float* smem) {
   int l = 0;
 #pragma unroll
   for (int q = 1; q < KB_MAX_LAYERS; ++q)
@@ -933,7 +933,10 @@ int rovit_head_phase_dw_launch(const rovit_head_phase* p, hipStream_t st) {
       a.nk[l] = p->kan_knots[l]; a.act[l] = p->kan_acts[l];
       a.dW[l] = p->kan_dw[l]; a.dlw[l] = p->kan_dlw[l]; a.dlb[l] = p->kan_dlb[l];
       const int nb = p->kan_knots[l] - 4;
-      int bc = (24 * 1024) / (nb + 1 + p->kan_dims[l + 1]);
+      // batch rows per LDS chunk: ~32 KB per workgroup here (rovit_kan_stack_bwd takes 96 KB), because the head linears' workgroups of
+      // the same grid reserve the same dynamic LDS and two 1024-thread workgroups should share a CU
+      int bc = (7 * 1024) / (nb + 1 + p->kan_dims[l + 1]);
+      bc = bc < 16 ? 16 : bc;
       bc = bc > B ? B : bc;
       a.bc[l] = bc;
       a.thr[l] = p->kan_dims[l + 1] * (nb + 2) >= 512 ? 1024 : 256;

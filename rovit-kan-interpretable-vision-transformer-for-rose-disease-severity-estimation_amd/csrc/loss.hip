@@ -17,7 +17,7 @@ constexpr int MAXC = 16;
 
 struct LossArgs {
   const float* cls; const float* ord; const float* mu; const float* lv; const float* kan;
-  const long long* cls_t; const float* sev_t; const float* alpha;
+  const long long* cls_t; const void* sev_t; int sev_i64; const float* alpha;
   float* d_cls; float* d_ord; float* d_mu; float* d_lv; float* d_kan;
   float* out;      // [5]: cls, ord, unc, kan, total
   int B, C;
@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(const LossArgs a) {
     const bool t_ok = t_raw >= 0 && t_raw < a.C;
     const int t = t_ok ? (int)t_raw : 0;
     if (!t_ok) l_cls = __builtin_nanf("");
-    const float y = a.sev_t[b];                                    // severity as float, like the reference (:89-90, :110-111)
+    // severity as float, like the reference's .float() casts (:89-90, :110-111); int64 labels are converted here, not by a copy launch
+    const float y = a.sev_i64 ? (float)((const long long*)a.sev_t)[b] : ((const float*)a.sev_t)[b];
     // ---- focal cross-entropy (losses.py:15-38) ----
     float z[MAXC];
     float zmax = -INFINITY;
@@ -116,15 +117,15 @@ __global__ __launch_bounds__(256) void scale_buffers_kernel(const ScaleArgs a) {
 // Inactive heads: pass NULL for (ord, d_ord) / (mu, lv, d_mu, d_lv) / (kan, d_kan) -- that is the curriculum gate.
 // d_* receive d(total)/d(output) for an upstream gradient of 1.  losses_out: [cls, ord, unc, kan, total].
 extern "C" int rovit_joint_loss(const float* cls_logits, const float* ordinal_logits, const float* mu, const float* log_var,
-                                const float* kan_severity, const long long* class_targets, const float* severity_targets,
-                                const float* focal_alpha, float* d_cls, float* d_ord, float* d_mu, float* d_lv, float* d_kan,
+                                const float* kan_severity, const long long* class_targets, const void* severity_targets,
+                                int severity_is_int64, const float* focal_alpha, float* d_cls, float* d_ord, float* d_mu, float* d_lv, float* d_kan,
                                 float* losses_out, int batch, int num_classes, float lambda_ord, float mu_unc, float nu_kan,
                                 float focal_gamma, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(cls_logits && class_targets && severity_targets && d_cls && losses_out, ROVIT_ERR_NULL, "joint_loss: null pointer");
   ROVIT_CHECK_ARG(batch > 0 && num_classes >= 2 && num_classes <= MAXC, ROVIT_ERR_SHAPE, "joint_loss: bad batch/classes");
   ROVIT_CHECK_ARG((!ordinal_logits || d_ord) && (!mu || (log_var && d_mu && d_lv)) && (!kan_severity || d_kan), ROVIT_ERR_NULL,
                   "joint_loss: gradient buffer missing for an active head");
-  LossArgs a{cls_logits, ordinal_logits, mu, log_var, kan_severity, class_targets, severity_targets, focal_alpha,
+  LossArgs a{cls_logits, ordinal_logits, mu, log_var, kan_severity, class_targets, severity_targets, severity_is_int64 ? 1 : 0, focal_alpha,
              d_cls, d_ord, d_mu, d_lv, d_kan, losses_out, batch, num_classes, lambda_ord, mu_unc, nu_kan, focal_gamma};
   hipLaunchKernelGGL(joint_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   ROVIT_CHECK_LAUNCH("joint_loss_kernel");

@@ -1078,10 +1078,11 @@ extern "C" size_t rovit_mlp_stream_bytes(void) { return (size_t)STREAM_ENTRIES *
 
 // (internal) streams of `depth` blocks laid out inside the prepared-weight buffer of rovit_vit_prepare
 int rovit_mlp_stream_prep_blocks(const void* prep_base, size_t blk0, size_t stride, size_t off_w1, size_t off_w2, size_t off_out,
-                                 size_t off_wp, int bwd, size_t off_wq_next, int depth, rovit_stream_t stream) {
+                                 size_t off_wp, int bwd, size_t off_wq_next, int depth, rovit_stream_t stream, bool gelu_tables) {
   const MlpPrepArgs a{(const char*)prep_base, blk0, stride, off_w1, off_w2, off_out, off_wp, bwd, off_wq_next, depth - 1};
   hipLaunchKernelGGL(mlp_stream_prep_kernel, dim3((STREAM_ENTRIES * CH_PIECES * 64 + 255) / 256, depth), dim3(256), 0, (hipStream_t)stream, a);
-  if (!bwd) hipLaunchKernelGGL(mlp_gelu_table_kernel, dim3(GT_ENTRIES / 256, depth), dim3(256), 0, (hipStream_t)stream, a);   // only the forward looks GELU up
+  // only the forward looks GELU up; the table does not depend on the weights: a caller that prepares the same buffer again may skip it
+  if (!bwd && gelu_tables) hipLaunchKernelGGL(mlp_gelu_table_kernel, dim3(GT_ENTRIES / 256, depth), dim3(256), 0, (hipStream_t)stream, a);
   ROVIT_CHECK_LAUNCH("mlp_stream_prep_kernel");
   return ROVIT_OK;
 }

@@ -216,8 +216,9 @@ extern "C" int rovit_vit_workspace_field(int batch, int depth, int field, int bl
 
 // Fold the LayerNorm affines, cast to bf16 and build the transposed copies the dgrad GEMMs read.
 // Must be re-run whenever the fp32 parameters change (every optimizer step).
-extern "C" int rovit_vit_prepare(const float* const* params, void* prep, int depth, rovit_stream_t stream) {
-  ROVIT_CHECK_ARG(params && prep && depth > 0, ROVIT_ERR_NULL, "vit_prepare: null pointer");
+namespace {
+// the patch-embedding weight on `s_patch` (the forward needs it first), every block's weights on `s_blocks`
+int vit_prepare_impl(const float* const* params, void* prep, int depth, rovit_stream_t s_patch, rovit_stream_t s_blocks, bool gelu_tables) {
   const Prep P(depth);
   char* pb = (char*)prep;
   std::vector<RovitPrepDesc> descs;
@@ -231,16 +232,29 @@ extern "C" int rovit_vit_prepare(const float* const* params, void* prep, int dep
     descs.push_back({bp[B_FC1W], bp[B_FC1B], bp[B_N2W], bp[B_N2B], q + P.wfc1, q + P.wfc1T, (float*)(q + P.bfc1), MLP, D});
     descs.push_back({bp[B_FC2W], nullptr, nullptr, nullptr, q + P.wfc2, q + P.wfc2T, nullptr, D, MLP});
   }
-  RUN(rovit_prep_weight_batch(descs.data(), (int)descs.size(), stream));
-  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc1, P.wfc2, P.wmlp, P.wproj, 0, P.blk_stride + P.wqkv, depth, stream));     // + proj and the NEXT block's qkv: the block-tail image
-  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc2T, P.wfc1T, P.wmlpb, P.wprojT, 1, ~(size_t)0, depth, stream));     // dgrad chain: (W2T, W1T) + WprojT: the backward block-tail image
+  if (s_patch == s_blocks) {
+    RUN(rovit_prep_weight_batch(descs.data(), (int)descs.size(), s_blocks));
+  } else {
+    RUN(rovit_prep_weight_batch(descs.data(), 1, s_patch));
+    RUN(rovit_prep_weight_batch(descs.data() + 1, (int)descs.size() - 1, s_blocks));
+  }
+  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc1, P.wfc2, P.wmlp, P.wproj, 0, P.blk_stride + P.wqkv, depth, s_blocks,
+                                   gelu_tables));     // + proj and the NEXT block's qkv: the block-tail image
+  RUN(rovit_mlp_stream_prep_blocks(prep, P.blk0, P.blk_stride, P.wfc2T, P.wfc1T, P.wmlpb, P.wprojT, 1, ~(size_t)0, depth, s_blocks));     // dgrad chain: (W2T, W1T) + WprojT: the backward block-tail image
   return ROVIT_OK;
+}
+}  // namespace
+
+extern "C" int rovit_vit_prepare(const float* const* params, void* prep, int depth, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(params && prep && depth > 0, ROVIT_ERR_NULL, "vit_prepare: null pointer");
+  return vit_prepare_impl(params, prep, depth, stream, stream, true);
 }
 
 namespace {
+// prepare: 0 = the weights in `prep` are current; 1 = prepare them from `params` first; 2 = ... and write the constant tables too
 int vit_forward_impl(const float* images, const float* const* params, const void* prep, void* workspace, float* features,
                      void* const* attn_taps, float* const* prob_taps, int batch, int depth, int training, int mlp_path,
-                     rovit_stream_t stream) {
+                     rovit_stream_t stream, int prepare = 0) {
   ROVIT_CHECK_ARG(images && features, ROVIT_ERR_NULL, "vit_forward: null images/features");
   RUN(check_common(params, prep, workspace, batch, depth, mlp_path));
   const Prep P(depth);
@@ -250,9 +264,23 @@ int vit_forward_impl(const float* images, const float* const* params, const void
   float* X = (float*)(ws + L.X);
   const int M = (int)L.M;
   const float eps = 1e-6f;
+  // Weight preparation inside the forward (rovit_vit_forward_prepare): four launches, 41 us per training step when they stand in front
+  // of the forward.  Only the patch-embedding weight is needed at once; the blocks' weights are prepared on the side stream BESIDE the
+  // patch embedding (59 us, bound by the fp32 pixels it reads), and the caller's stream waits for them in front of block 0.
+  SideStream* ss_prep = (prepare && two_streams_enabled() && !attn_taps && !prob_taps && batch >= 16) ? side_stream() : nullptr;
+  hipEvent_t ev_prep = nullptr;
+  if (prepare) {
+    if (ss_prep) {
+      ss_prep->next = 0;
+      if (!hand_over(ss_prep, (hipStream_t)stream, ss_prep->stream)) { rovit_set_error("vit_forward: event hand-over failed"); return ROVIT_ERR_LAUNCH; }
+    }
+    RUN(vit_prepare_impl(params, const_cast<void*>(prep), depth, stream, ss_prep ? (rovit_stream_t)ss_prep->stream : stream, prepare == 2));
+    if (ss_prep && !(ev_prep = hand_over(ss_prep, ss_prep->stream, nullptr, true))) { rovit_set_error("vit_forward: event record failed"); return ROVIT_ERR_LAUNCH; }
+  }
   RUN(rovit_cls_rows(params[P_CLS], params[P_POS], X, batch, T, stream));
   // PatchEmbed: the GEMM gathers its A tiles from the images (no im2col buffer: 77 MB and one 42 us launch less per step)
   RUN(rovit_patch_embed_fwd(images, pb + P.wpe, params[P_PATCH_B], params[P_POS], X, batch, T, stream));
+  if (ev_prep && hipStreamWaitEvent((hipStream_t)stream, ev_prep, 0) != hipSuccess) { rovit_set_error("vit_forward: event wait failed"); return ROVIT_ERR_LAUNCH; }
   // Samples are independent in the forward pass, so the batch is cut into two halves that run the same kernel
   // chain on two HIP streams with no synchronisation until the final norm: every kernel here is a 20-50 us
   // persistent launch with ~6 us of ramp (dispatch, weight prologue, first tile, tail), which the other half's
@@ -262,7 +290,7 @@ int vit_forward_impl(const float* images, const float* const* params, const void
   Half halves[2] = {{0, ss ? (batch + 1) / 2 : batch, stream}, {(batch + 1) / 2, ss ? batch / 2 : 0, ss ? (rovit_stream_t)ss->stream : stream}};
   const int nh = ss ? 2 : 1;
   if (ss) {
-    ss->next = 0;
+    if (!ss_prep) ss->next = 0;        // (the preparation above has taken events of this call already)
     if (!hand_over(ss, (hipStream_t)stream, ss->stream)) { rovit_set_error("vit_forward: event hand-over failed"); return ROVIT_ERR_LAUNCH; }
     rovit_set_cu_budget(128);
   }
@@ -367,6 +395,15 @@ int vit_forward_impl(const float* images, const float* const* params, const void
 extern "C" int rovit_vit_forward(const float* images, const float* const* params, const void* prep, void* workspace,
                                  float* features, int batch, int depth, int training, int mlp_path, rovit_stream_t stream) {
   return vit_forward_impl(images, params, prep, workspace, features, nullptr, nullptr, batch, depth, training, mlp_path, stream);
+}
+
+// rovit_vit_prepare + rovit_vit_forward as ONE call (a training step prepares the weights after every optimizer step): the blocks'
+// weight images are written beside the patch embedding instead of in front of the forward.  write_tables != 0: also (re)write the
+// constant look-up tables of `prep` (needed once per buffer; rovit_vit_prepare always writes them).
+extern "C" int rovit_vit_forward_prepare(const float* images, const float* const* params, void* prep, void* workspace, float* features,
+                                         int batch, int depth, int training, int mlp_path, int write_tables, rovit_stream_t stream) {
+  return vit_forward_impl(images, params, prep, workspace, features, nullptr, nullptr, batch, depth, training, mlp_path, stream,
+                          write_tables ? 2 : 1);
 }
 
 // Same forward (inference workspace), additionally writing each block's attention-module output into

@@ -198,6 +198,23 @@ class HeadPhaseFn(torch.autograd.Function):
     grad_views: optional {param.data_ptr(): tensor} of flat-buffer views the parameter gradients may be written into directly.
     outputs: cls, ord, mu, log_var, kan (the last KAN layer's output); inactive ones are zero-size placeholders."""
 
+    _streams = {}          # device index -> the stream the parameter-gradient launch runs on
+    _pending = {}          # device index -> event recorded behind the most recent parameter-gradient launch (until waited for)
+
+    @staticmethod
+    def param_grad_stream(dev):
+        s = HeadPhaseFn._streams.get(dev.index)
+        if s is None:
+            s = HeadPhaseFn._streams[dev.index] = torch.cuda.Stream(device=dev)
+        return s
+
+    @staticmethod
+    def wait_param_grads(dev, stream=None):
+        """Make `stream` (default: the current one) wait for the head / KAN parameter gradients of the backward in flight."""
+        ev = HeadPhaseFn._pending.pop(dev.index, None) if stream is None else HeadPhaseFn._pending.get(dev.index)
+        if ev is not None:
+            (stream if stream is not None else torch.cuda.current_stream(dev)).wait_event(ev)
+
     @staticmethod
     def _desc(features, cfg, head_params, kan_params):
         import ctypes as C
@@ -318,8 +335,24 @@ class HeadPhaseFn(torch.autograd.Function):
                 d.head_grads[i] = ptr(grads[i])
             for l in range(nl):
                 d.kan_dw[l], d.kan_dlw[l], d.kan_dlb[l] = (ptr(grads[14 + 3 * l + q]) for q in range(3))
-        d.want_param_grads = int(want)
+        side = HeadPhaseFn.param_grad_stream(dev) if (want and cfg.get('dw_side_stream', True)) else None
+        d.want_param_grads = int(want and side is None)
         call('rovit_head_phase_bwd', C.byref(d), stream_ptr())
+        if side is not None:
+            # The parameter gradients are sample sums nobody waits for before the optimizer (or the data-parallel bucket): their launch
+            # goes to a stream of its own, beside the backbone's backward, and the caller's stream is made to wait for it when the whole
+            # backward pass ends (autograd's final callbacks run on the stream that surrounded .backward(), like DDP's).
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                call('rovit_head_phase_bwd_params', C.byref(d), stream_ptr())
+            for t in (features, hidden, lv, *kouts, g_cls, g_ord, g_mu, g_lv, g_kan, scratch, *(g for g in grads if g is not None)):
+                if t is not None and t.numel():
+                    t.record_stream(side)
+            done = torch.cuda.Event()
+            done.record(side)
+            HeadPhaseFn._pending[dev.index] = done
+            from torch.autograd import Variable
+            Variable._execution_engine.queue_callback(lambda: HeadPhaseFn.wait_param_grads(dev))
         del keep
         out = [g if n else None for g, n in zip(grads, need)]
         return (dfeat, None, *out)
@@ -410,16 +443,25 @@ class VitEngine:
         self.last_ws = None              # (workspace, batch) of the most recent training-mode forward (read by rovit_hip.taps)
 
     # -- prepared weights ---------------------------------------------------------------------
-    def prepare(self, params: Sequence[torch.Tensor]):
+    def prepare(self, params: Sequence[torch.Tensor], defer: bool = False) -> int:
+        """Bring the bf16 weight images in line with `params`.  defer=True (the training forward): nothing is launched here; the
+        return value tells the caller to use rovit_vit_forward_prepare (1; 2 = this buffer's constant tables are not written yet),
+        which prepares the blocks' weights beside the patch embedding.  0: the images are current."""
         key = tuple((p.data_ptr(), p._version) for p in params)
         if key == self._prep_key:
-            return
+            return 0
         dev = params[0].device
         lib = native.load()
         if self.prep is None or self.prep.device != dev:
             self.prep = torch.empty(lib.rovit_vit_prep_bytes(self.depth), dtype=torch.uint8, device=dev)
-        call('rovit_vit_prepare', ptr_array(params), ptr(self.prep), self.depth, stream_ptr())
+            self._tables_written = False
         self._prep_key = key
+        mode = 1 if getattr(self, '_tables_written', False) else 2
+        self._tables_written = True
+        if defer:
+            return mode
+        call('rovit_vit_prepare', ptr_array(params), ptr(self.prep), self.depth, stream_ptr())
+        return 0
 
     # -- workspaces ---------------------------------------------------------------------------
     def take_ws(self, batch: int, training: bool, dev) -> torch.Tensor:
@@ -462,7 +504,7 @@ class VitFn(torch.autograd.Function):
             raise native.RovitHipError(f'backbone expects (B,3,224,224) images, got {tuple(images.shape)}')
         B = images.shape[0]
         dev = images.device
-        engine.prepare(params)
+        prep_mode = engine.prepare(params, defer=True)
         need_bwd = training and any(p.requires_grad for p in params) and torch.is_grad_enabled()
         # (inside Function.forward grad mode is disabled; the caller passes the real flag via `training`)
         need_bwd = training and any(p.requires_grad for p in params)
@@ -470,8 +512,16 @@ class VitFn(torch.autograd.Function):
         feats = torch.empty(B, 192, device=dev, dtype=torch.float32)
         parr = ptr_array(params)
         mlp_path = int(engine.mlp_path if engine.mlp_path is not None else VitEngine.default_mlp_path)
-        call('rovit_vit_forward', ptr(images), parr, ptr(engine.prep), ptr(ws), ptr(feats), B, engine.depth,
-             int(need_bwd), mlp_path, stream_ptr())
+        if prep_mode:        # the parameters changed (optimizer step): prepare the weight images inside the forward call
+            try:
+                call('rovit_vit_forward_prepare', ptr(images), parr, ptr(engine.prep), ptr(ws), ptr(feats), B, engine.depth,
+                     int(need_bwd), mlp_path, int(prep_mode == 2), stream_ptr())
+            except Exception:
+                engine._prep_key, engine._tables_written = None, False       # nothing can be assumed about the images
+                raise
+        else:
+            call('rovit_vit_forward', ptr(images), parr, ptr(engine.prep), ptr(ws), ptr(feats), B, engine.depth,
+                 int(need_bwd), mlp_path, stream_ptr())
         ctx.engine, ctx.batch, ctx.need_bwd, ctx.mlp_path = engine, B, need_bwd, mlp_path
         if need_bwd:
             ctx.ws = ws

@@ -27,16 +27,20 @@ class JointLossFn(torch.autograd.Function):
         f = lambda t: None if t is None else t.detach().float().contiguous()
         cls, ordl, mu, lv, kan = f(cls), f(ordl), f(mu), f(lv), f(kan)
         cls_t = cls_t.long().contiguous()
-        sev_t = sev_t.detach().float().reshape(-1).contiguous()      # severity stays float (reference losses.py:89-90,110-111)
+        # severity is used as float (reference losses.py:89-90,110-111): int64 labels are converted inside the kernel, anything else here
+        sev_t = sev_t.detach().reshape(-1)
+        sev_i64 = sev_t.dtype == torch.int64
+        sev_t = (sev_t if sev_i64 else sev_t.float()).contiguous()
         alpha = f(alpha.to(cls.device)) if alpha is not None else None
         B, C = cls.shape
         out = torch.empty(5, device=cls.device, dtype=torch.float32)
         grads = [torch.empty_like(t) if t is not None else None for t in (cls, ordl, mu, lv, kan)]
         lam, muw, nu, gamma = weights
-        call('rovit_joint_loss', ptr(cls), ptr(ordl), ptr(mu), ptr(lv), ptr(kan), ptr(cls_t), ptr(sev_t), ptr(alpha),
+        call('rovit_joint_loss', ptr(cls), ptr(ordl), ptr(mu), ptr(lv), ptr(kan), ptr(cls_t), ptr(sev_t), int(sev_i64), ptr(alpha),
              ptr(grads[0]), ptr(grads[1]), ptr(grads[2]), ptr(grads[3]), ptr(grads[4]), ptr(out), B, C, lam, muw, nu, gamma,
              stream_ptr())
         ctx.grads = grads
+        ctx.set_materialize_grads(False)      # no zeros(4) launch for the (non-differentiable) components' gradient
         comps = out[:4]
         ctx.mark_non_differentiable(comps)
         return out[4], comps
@@ -46,6 +50,8 @@ class JointLossFn(torch.autograd.Function):
         if ctx.grads is None:
             raise native.RovitHipError('JointLoss: backward called twice on the same graph (the fused kernel scales its '
                                        'gradient buffers in place); call the loss again instead of retain_graph=True')
+        if g_total is None:
+            return (None,) * 9
         grads, ctx.grads = ctx.grads, None
         live = [g for g in grads if g is not None]
         arr = (ctypes.c_void_p * len(live))(*[g.data_ptr() for g in live])

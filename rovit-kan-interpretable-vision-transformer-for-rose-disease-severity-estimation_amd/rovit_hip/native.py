@@ -15,7 +15,7 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get('ROVIT_HIP_LIB') or os.path.join(_PKG_ROOT, 'lib', 'librovit_hip.so')   # env override: developer A/B builds
 
 _lib: Optional[C.CDLL] = None
-ABI_VERSION = 400          # rovit_version() this binding matches (csrc/api.hip)
+ABI_VERSION = 410          # rovit_version() this binding matches (csrc/api.hip)
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -43,6 +43,7 @@ SIGNATURES = {
     'rovit_heads_bwd': (_i, [_vp] * 12 + [_i] * 5 + [_vp]),
     'rovit_head_phase_fwd': (_i, [_vp, _vp]),
     'rovit_head_phase_bwd': (_i, [_vp, _vp]),
+    'rovit_head_phase_bwd_params': (_i, [_vp, _vp]),
     'rovit_vit_num_params': (_i, [_i]),
     'rovit_vit_prep_bytes': (_sz, [_i]),
     'rovit_vit_workspace_bytes': (_sz, [_i, _i, _i]),
@@ -51,6 +52,7 @@ SIGNATURES = {
     'rovit_vit_workspace_field': (_i, [_i, _i, _i, _i, _vp, _vp]),
     'rovit_vit_prepare': (_i, [_vp, _vp, _i, _vp]),
     'rovit_vit_forward': (_i, [_vp] * 5 + [_i] * 4 + [_vp]),
+    'rovit_vit_forward_prepare': (_i, [_vp] * 5 + [_i] * 5 + [_vp]),
     'rovit_vit_forward_taps': (_i, [_vp] * 7 + [_i, _i, _vp]),
     'rovit_attention_probs': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     'rovit_vit_backward': (_i, [_vp] * 6 + [_i] * 5 + [_vp]),
@@ -82,12 +84,14 @@ SIGNATURES = {
     'rovit_cls_norm_bwd': (_i, [_vp] * 8 + [_i, _i, _i, _vp]),
     'rovit_pos_grad': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     'rovit_prep_weight': (_i, [_vp] * 7 + [_i, _i, _vp]),
-    'rovit_joint_loss': (_i, [_vp] * 14 + [_i, _i, _f, _f, _f, _f, _vp]),
+    'rovit_joint_loss': (_i, [_vp] * 7 + [_i] + [_vp] * 7 + [_i, _i, _f, _f, _f, _f, _vp]),
     'rovit_scale_buffers': (_i, [_vp, _vp, _i, _vp, _vp]),
     'rovit_sq_norm_accum': (_i, [_vp, _sz, _vp, _vp, _vp]),
     'rovit_mix_images': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp]),
     'rovit_clip_coef': (_i, [_vp, _f, _vp, _vp, _vp]),
     'rovit_adamw_flat': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _i, _vp]),
+    'rovit_sq_norm_clip': (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    'rovit_adamw_flat_multi': (_i, [_vp] * 7 + [_i, _vp, _f, _f, _f, _f, _vp]),
 }
 
 

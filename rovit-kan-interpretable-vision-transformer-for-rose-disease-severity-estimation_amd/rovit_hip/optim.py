@@ -116,7 +116,8 @@ class RoViTAdamW(torch.optim.Optimizer):
             for dst, src in zip((self.m_flat, self.v_flat, self.o_m, self.o_v), old):
                 dst.copy_(src)
         self._sq = torch.zeros((), dtype=torch.float32, device=dev)
-        self._sq_scratch = torch.zeros(520, dtype=torch.float32, device=dev)     # fixed-order block partials (bit-reproducible norm)
+        # ticket + fixed-order block partials of rovit_sq_norm_clip (one per 4096 gradient floats; bit-reproducible norm)
+        self._sq_scratch = torch.zeros(16 + (self._bb_total + 4095) // 4096 + (self._o_total + 4095) // 4096 + 8, dtype=torch.float32, device=dev)
         self._coef = torch.ones((), dtype=torch.float32, device=dev)
         self._norm = torch.zeros((), dtype=torch.float32, device=dev)
         self.engine._prep_key = None
@@ -155,6 +156,9 @@ class RoViTAdamW(torch.optim.Optimizer):
                     dst.append(v); src.append(g)
             active.append(s)
         if dst:
+            if dst[0].is_cuda:           # gradients that are still being written on the head phase's own stream (functions.HeadPhaseFn)
+                from .functions import HeadPhaseFn
+                HeadPhaseFn.wait_param_grads(dst[0].device)
             torch._foreach_copy_(dst, src)
         return active
 
@@ -197,23 +201,33 @@ class RoViTAdamW(torch.optim.Optimizer):
         if bb and (eng.grad_views is None or self.bb_params[0].grad.data_ptr() != eng.grad_views[0].data_ptr()):
             raise native.RovitHipError('backbone gradients are not the engine-owned flat buffer')
         active = self._pack_grads()
+        import ctypes as C
         coef = None
         if self.max_grad_norm is not None:
-            self._sq.zero_()
-            if bb:
-                call('rovit_sq_norm_accum', ptr(eng.grad_flat), eng.grad_flat.numel(), ptr(self._sq), ptr(self._sq_scratch), sp)
-            for first, last in self._runs(active):      # padding floats of o_grad stay zero: sum whole aligned runs
-                call('rovit_sq_norm_accum', ptr(self.o_grad[first.offset:]),
-                     last.offset + last.numel - first.offset, ptr(self._sq), ptr(self._sq_scratch), sp)
-            call('rovit_clip_coef', ptr(self._sq), float(self.max_grad_norm), ptr(self._coef), ptr(self._norm), sp)
-            self.last_grad_norm = self._norm
-            coef = ptr(self._coef)
+            # clip_grad_norm_ in ONE launch: squared norm over the backbone's flat buffer and the live runs of o_grad (padding floats
+            # stay zero: whole aligned runs are summed), block partials in fixed order, then the coefficient
+            bufs = [(eng.grad_flat, eng.grad_flat.numel())] if bb else []
+            bufs += [(self.o_grad[first.offset:], last.offset + last.numel - first.offset) for first, last in self._runs(active)]
+            if bufs and len(bufs) <= 4:
+                arr = (C.c_void_p * len(bufs))(*[ptr(b) for b, _ in bufs])
+                cnt = (C.c_size_t * len(bufs))(*[n for _, n in bufs])
+                call('rovit_sq_norm_clip', arr, cnt, len(bufs), float(self.max_grad_norm), ptr(self._coef), ptr(self._norm),
+                     ptr(self._sq_scratch), self._sq_scratch.numel(), sp)
+            elif bufs:                                    # many disjoint runs (a model with many gated modules): one launch per run
+                self._sq.zero_()
+                for b, n in bufs:
+                    call('rovit_sq_norm_accum', ptr(b), n, ptr(self._sq), None, sp)
+                call('rovit_clip_coef', ptr(self._sq), float(self.max_grad_norm), ptr(self._coef), ptr(self._norm), sp)
+            if bufs:
+                self.last_grad_norm = self._norm
+                coef = ptr(self._coef)
+        # AdamW over the backbone and every run of active segments that share a step count: ONE launch
+        segs = []
+        hyper = lambda g_: (float(g_['betas'][0]), float(g_['betas'][1]), float(g_['eps']), float(g_['weight_decay']))
         if bb:
             self.t += 1
-            call('rovit_adamw_flat', ptr(self.p_flat), ptr(eng.grad_flat), ptr(self.m_flat), ptr(self.v_flat),
-                 self.p_flat.numel(), coef, float(gb['lr']), gb['betas'][0], gb['betas'][1], gb['eps'], gb['weight_decay'], self.t, sp)
+            segs.append((self.p_flat, eng.grad_flat, self.m_flat, self.v_flat, self.p_flat.numel(), float(gb['lr']), self.t, hyper(gb)))
             eng._prep_key = None            # parameters changed behind torch's version counters: re-prepare weights
-        # consecutive active segments with the same step count share one launch (the usual case: all of them)
         if active and hasattr(self.model, 'kan_module') and hasattr(self.model.kan_module, 'invalidate_prepared'):
             self.model.kan_module.invalidate_prepared()      # parameters change behind torch's version counters
         for first, last in self._runs(active, same_t=True):
@@ -221,8 +235,16 @@ class RoViTAdamW(torch.optim.Optimizer):
             for s in active[active.index(first):active.index(last) + 1]:
                 s.t += 1
             o = first.offset
-            call('rovit_adamw_flat', ptr(self.o_flat[o:]), ptr(self.o_grad[o:]), ptr(self.o_m[o:]), ptr(self.o_v[o:]), n, coef,
-                 float(gh['lr']), gh['betas'][0], gh['betas'][1], gh['eps'], gh['weight_decay'], first.t, sp)
+            segs.append((self.o_flat[o:], self.o_grad[o:], self.o_m[o:], self.o_v[o:], n, float(gh['lr']), first.t, hyper(gh)))
+        # (one launch when the groups share betas / eps / weight decay, as the reference's do; else one per distinct setting)
+        for hp in dict.fromkeys(c[7] for c in segs):
+            same = [c for c in segs if c[7] == hp]
+            for i in range(0, len(same), 4):
+                chunk = same[i:i + 4]
+                pa = lambda k: (C.c_void_p * len(chunk))(*[ptr(c[k]) for c in chunk])
+                call('rovit_adamw_flat_multi', pa(0), pa(1), pa(2), pa(3), (C.c_size_t * len(chunk))(*[c[4] for c in chunk]),
+                     (C.c_float * len(chunk))(*[c[5] for c in chunk]), (C.c_int * len(chunk))(*[c[6] for c in chunk]), len(chunk), coef,
+                     hp[0], hp[1], hp[2], hp[3], sp)
         return loss
 
     @staticmethod

@@ -180,6 +180,14 @@ class GradSync:
         grads = [p.grad for p in self.other_params if p.grad is not None]
         if not grads:
             return None
+        if grads[0].is_cuda:
+            # the fused head phase computes these gradients on a stream of its own (functions.HeadPhaseFn): whoever reads them before
+            # the backward pass has ended -- this bucket does -- waits for that launch first
+            from .functions import HeadPhaseFn
+            # with a flat optimizer buffer the reduction stream waits and the backward's own stream does not; the flatten copy below runs
+            # on the backward's stream, which then has to wait itself
+            rs = self.reducer.stream_for(grads[0].device) if (self.reducer.use_side_stream and self.optimizer is not None) else None
+            HeadPhaseFn.wait_param_grads(grads[0].device, rs)
         if self.optimizer is not None:
             for off, n in self.optimizer.pack_and_install_grads():       # param.grad are views of o_grad from here on
                 self.reducer.reduce_slice(self.optimizer.o_grad, off, n)

@@ -233,3 +233,63 @@ def test_training_step_uses_the_fused_phase_and_writes_gradients_into_the_optimi
     assert not m._head_phase_fusable(torch.zeros(4, 192, device=dev()))
     h.remove()
     assert m._head_phase_fusable(torch.zeros(4, 192, device=dev()))
+
+
+def test_parameter_gradients_on_their_own_stream_equal_the_inline_launch():
+    """The head / KAN parameter gradients are computed on a side stream and joined by an autograd final callback: over several steps
+    (optimizer included) every parameter stays bit-identical to a run with the launch inline on the backward's stream."""
+    from models.rovit_kan import RoViTKAN
+    from rovit_hip.functions import HeadPhaseFn
+    from rovit_hip.losses import JointLoss
+    from rovit_hip.optim import RoViTAdamW
+    x = torch.randn(8, 3, 224, 224, device=dev())
+    y = torch.randint(0, 4, (8,), device=dev())
+    finals = []
+    for side in (True, False):
+        torch.manual_seed(5)
+        m = RoViTKAN(pretrained=False, dropout=0.3).to(dev()).train()
+        opt = RoViTAdamW(m, lr=1e-3)
+        loss_fn = JointLoss(1.0, 0.5, 0.5, 2.0)
+        orig = m._forward_head_phase
+        if not side:
+            import functools
+            real_apply = HeadPhaseFn.apply
+
+            def no_side(features, cfg, *params, _real=real_apply):
+                return _real(features, dict(cfg, dw_side_stream=False), *params)
+            HeadPhaseFn.apply = staticmethod(no_side)
+        try:
+            for _ in range(4):
+                opt.zero_grad(set_to_none=True)
+                loss_fn(m(x), y, y, 4)['total_loss'].backward()
+                assert (not side) or HeadPhaseFn._pending.get(0) is None        # the final callback consumed the event
+                opt.step()
+        finally:
+            if not side:
+                HeadPhaseFn.apply = real_apply
+        torch.cuda.synchronize()
+        finals.append({n: p.detach().clone() for n, p in m.named_parameters()})
+    for n in finals[0]:
+        assert torch.equal(finals[0][n], finals[1][n]), n
+
+
+def test_joint_loss_takes_int64_severity_labels_without_a_cast_launch():
+    from rovit_hip.losses import JointLoss
+    g = torch.Generator().manual_seed(3)
+    out = {'cls_logits': torch.randn(19, 4, generator=g).to(dev()).requires_grad_(True),
+           'ordinal_logits': torch.randn(19, 3, generator=g).to(dev()).requires_grad_(True),
+           'mu': torch.randn(19, 1, generator=g).to(dev()).requires_grad_(True), 'log_var': torch.randn(19, 1, generator=g).to(dev()).requires_grad_(True),
+           'kan_severity': (3 * torch.rand(19, 1, generator=g)).to(dev()).requires_grad_(True)}
+    y = torch.randint(0, 4, (19,), generator=g).to(dev())
+    loss_fn = JointLoss(1.0, 0.5, 0.5, 2.0)
+    a = loss_fn(out, y, y, 4)
+    a['total_loss'].backward()
+    ga = {k: v.grad.clone() for k, v in out.items()}
+    for v in out.values():
+        v.grad = None
+    b = loss_fn(out, y, y.float(), 4)
+    b['total_loss'].backward()
+    for k in ('cls_loss', 'ord_loss', 'unc_loss', 'kan_loss', 'total_loss'):
+        assert torch.equal(a[k], b[k]), k
+    for k, v in out.items():
+        assert torch.equal(ga[k], v.grad), k

@@ -9,9 +9,9 @@ import csv, glob
 f = glob.glob("$OUT/kseq/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
-# last step = after the last adamw pair but one
-idx = [i for i, n in enumerate(names) if 'adamw_flat_kernel' in n]
-lo = idx[-3] + 1 if len(idx) >= 3 else 0
+# last step = behind the last AdamW launch but one
+idx = [i for i, n in enumerate(names) if 'adamw_multi_kernel' in n]      # one AdamW launch per step (round 4)
+lo = idx[-2] + 1 if len(idx) >= 2 else 0
 prev_end = None
 for r in rows[lo:idx[-1] + 1]:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])

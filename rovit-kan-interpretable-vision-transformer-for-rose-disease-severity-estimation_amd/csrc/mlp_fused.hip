@@ -61,6 +61,7 @@ constexpr int PIECE = 512;                    // bf16 elements of a 1 KB piece (
 constexpr int CH_PIECES = 24;                 // 12 first-GEMM fragments (2 tiles x 6 k-steps) + 12 second-GEMM fragments (12 output tiles)
 constexpr int CH_ELEMS = CH_PIECES * PIECE;   // 24 KB of weights per chunk
 constexpr int NSLOT = 3;
+constexpr int TAIL_WAVES_DEFAULT = 8;     // waves per workgroup of the forward block tail (16: one row tile per wave)
 // pipelined forward: ring entry j carries the fc2 fragments of hidden chunk j - PSKEW next to the fc1 fragments of chunk j.
 // PSKEW = 2: iteration j issues fc1 of chunk j, the GELU look-ups of chunk j - 1 and fc2 of chunk j - 2 -- three mutually
 // independent streams of work (matrix, vector + LDS gather, matrix); 1: fc2 of chunk j - 1 behind its own GELU.
@@ -145,29 +146,42 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // the scheduler can put the vector work and the LDS gathers into the matrix pipe's shadow.  The GELU itself is a table look-up
 // (GT_*).  The first iterations' GELU / fc2 run on zeros and the last ones' fc1 on zero blocks; stores of chunks that do not
 // exist are sent out of range (dropped, but counted).
-template <int KIND, int MODE, int NW, bool STAG = false, bool PIPE = false, bool TAIL = false>
-__global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) {
+// TPW (tiles per wave) = 1, NW = 16 (round 4, forward block tail only): SIXTEEN waves of ONE 16-row tile each -- four waves per SIMD
+// instead of two.  With two waves per SIMD the kernel runs as the SUM of its matrix, vector and LDS time (34 + 30 + 33 % of the
+// launch, profiles/r04_pmc_sq.json): both waves of a SIMD sit in the same phase of the same iteration.  Four waves (<= 128 registers:
+// the fc2 accumulators of one tile are 48, not 96) give the scheduler matrix work of one wave for the vector / LDS work of another.
+// Price: a weight fragment read from LDS serves one row tile instead of two (LDS reads x 2).  MEASURED (tools/ab_tail.sh, one box,
+// M = 50 432): 97.5 against 92.6 us for the training launch, 87.9 against 84.0 for inference -- bit-identical outputs, SLOWER: the
+// doubled fragment reads and the 16-wave barrier cost more than the occupancy gives.  Kept in the developer library (knob 18) only.
+template <int KIND, int MODE, int NW, bool STAG = false, bool PIPE = false, bool TAIL = false, int TPW = 2>
+__global__ __launch_bounds__(NW * 64, TPW == 1 ? 4 : 2) void mlp_fused_kernel(const MlpArgs g) {
+  static_assert(TPW == 2 || (TPW == 1 && PIPE && TAIL && KIND == 0 && NW == 16), "one tile per wave: the 16-wave forward block tail");
   static_assert(!TAIL || PIPE || KIND == 1, "the forward block tail builds on the pipelined forward");
   constexpr int NBIAS = HID + D + (TAIL ? D + 3 * D : 0);       // floats behind the ring: b1, b2 [, proj bias, next block's qkv bias]
   static_assert(!STAG || (KIND == 0 && NW == 8), "the staggered schedule is the 8-wave forward's");
-  static_assert(!PIPE || (KIND == 0 && NW == 8 && !STAG), "the pipelined schedule is the 8-wave forward's");
-  constexpr int S = 2 * MODE;                 // stores one wave issues per chunk
-  constexpr int ROWS = 32 * NW;               // rows per workgroup: wave w owns the 16-row tiles w and w + NW
-  constexpr int PW = CH_PIECES / NW + (KIND ? 2 : 0);   // DMA pieces one wave issues per chunk
+  static_assert(!PIPE || (KIND == 0 && (NW == 8 || NW == 16) && !STAG), "the pipelined schedule is the 8- / 16-wave forward's");
+  constexpr int S = TPW * MODE;               // stores one wave issues per chunk
+  constexpr int ROWS = 16 * TPW * NW;         // rows per workgroup: wave w owns the 16-row tiles w and w + NW
+  // DMA pieces one wave issues per chunk: 24 / NW, or (NW = 16) two for waves 0-7 and one for waves 8-15 -- the counted waits differ by wave
+  constexpr int PWHI = (CH_PIECES + NW - 1) / NW, PWLO = CH_PIECES / NW, PWREM = CH_PIECES % NW;
+  constexpr int PW = PWLO + (KIND ? 2 : 0);
+#define WAIT_DMA(extra) do { if (PWHI == PWLO || w >= PWREM) wait_vm<PWLO + (KIND ? 2 : 0) + (extra)>(); else wait_vm<PWHI + (KIND ? 2 : 0) + (extra)>(); } while (0)
   constexpr int SLOT = slot_elems(KIND, NW);
   constexpr int J0 = (TAIL && !KIND) ? TPROJ : 0;                  // forward block tail: ring entries in front of the MLP image
   const int NTOT = PENTRIES + J0 + ((TAIL && !KIND && g.qkv) ? TQKV : 0);   // ... and in all (wave-uniform)
   extern __shared__ __attribute__((aligned(16))) bf16 lds[];   // ONE array: ring / staged tile, then the two biases
-  float* s_bias = (float*)(lds + region_elems(KIND, NW));       // forward: [768] b1, [192] b2
+  // the ring (aliased by the generic epilogue's staged output tile; the one-tile-per-wave block tail stages nothing)
+  constexpr int REGION = TPW == 1 ? NSLOT * slot_elems(KIND, NW) : region_elems(KIND, NW);
+  float* s_bias = (float*)(lds + REGION);       // forward: [768] b1, [192] b2
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
   const int r0 = blockIdx.x * g.rpw;
 
   // this wave's rows: tile i holds rows r0 + 16 (w + NW i) + l15 (clamped for the loads; stores are bounds-checked)
-  int mrow[2], mcl[2];
+  int mrow[TPW], mcl[TPW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < TPW; ++i) {
     const int local = 16 * NW * i + 16 * w + l15;
     mrow[i] = local < g.rpw ? r0 + local : 0x3FFFFFFF;      // rows this workgroup does not own count as beyond M
     mcl[i] = mrow[i] < g.M ? mrow[i] : g.M - 1;
@@ -175,10 +189,11 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
   auto dma = [&](int chunk, int slot) {
     const bf16* src = g.wstream + (size_t)chunk * CH_ELEMS + lane * 8;
 #pragma unroll
-    for (int q = 0; q < CH_PIECES / NW; ++q) {
+    for (int q = 0; q < PWHI; ++q) {
       const int piece = w + NW * q;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * PIECE),
-                                       (__attribute__((address_space(3))) void*)(lds + slot * SLOT + piece * PIECE), 16, 0, 0);
+      if (PWHI == PWLO || piece < CH_PIECES)          // wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * PIECE),
+                                         (__attribute__((address_space(3))) void*)(lds + slot * SLOT + piece * PIECE), 16, 0, 0);
     }
     if (KIND) {        // this wave's own gelu' pieces: lane (row l15, q = lg) <- gelu'[row][32 chunk + 8 q .. +7]
 #pragma unroll
@@ -195,9 +210,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
     else v = g.bq ? ((const float4*)g.bq)[tid - (HID + 2 * D) / 4] : make_float4(0.f, 0.f, 0.f, 0.f);
     ((float4*)s_bias)[tid] = v;
   }
-  bf16x8 xf[2][6];
+  bf16x8 xf[TPW][6];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TPW; ++i)
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) xf[i][ks] = *(const bf16x8*)(g.xin + (size_t)mcl[i] * D + ks * 32 + lg * 8);
   // buffer resources for the kept activations: rows >= M fall outside num_records and are dropped by the hardware
@@ -213,15 +228,15 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
   if (TAIL && !KIND) r_qkv = __builtin_amdgcn_make_buffer_rsrc((void*)g.qkv, 0, g.qkv ? (int)((size_t)g.M * 3 * D * 2) : 0, 0x00020000);
   if (MODE >= 1) r_act = __builtin_amdgcn_make_buffer_rsrc((void*)g.act, 0, nrec, 0x00020000);
   if (MODE == 2) r_dact = __builtin_amdgcn_make_buffer_rsrc((void*)g.dact, 0, nrec, 0x00020000);
-  unsigned soff[2];
+  unsigned soff[TPW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) soff[i] = mrow[i] < g.M ? (unsigned)mrow[i] * (HC * 2) + lg * 16 : 0xF0000000u;
+  for (int i = 0; i < TPW; ++i) soff[i] = mrow[i] < g.M ? (unsigned)mrow[i] * (HC * 2) + lg * 16 : 0xF0000000u;
 
-  f32x4 a2[12][2];
+  f32x4 a2[12][TPW];
 #pragma unroll
   for (int ot = 0; ot < 12; ++ot)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TPW; ++i) {
       if constexpr (TAIL && KIND == 0) {        // the residual stream itself, in the (permuted) accumulator layout: everything is accumulated onto it
         const float4 x = *(const float4*)(g.X + (size_t)mcl[i] * D + tail_col(ot, 4 * lg));
         a2[ot][i] = (f32x4){x.x, x.y, x.z, x.w};
@@ -233,13 +248,13 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
       }
     }
 
-  const bf16* gtab = lds + region_elems(KIND, NW) + 2 * NBIAS;       // PIPE: the GELU table (behind the biases)
+  const bf16* gtab = lds + REGION + 2 * NBIAS;       // PIPE: the GELU table (behind the biases)
   if constexpr (PIPE) {
     const bf16* src = g.gelu_table + lane * 8;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)                                          // 32 pieces of 1 KB: 8 waves x 4 (older than the ring's first DMA)
+    for (int r = 0; r < 32 / NW; ++r)                                    // 32 pieces of 1 KB: 8 waves x 4 / 16 x 2 (older than the ring's first DMA)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (r * NW + w) * PIECE),
-                                       (__attribute__((address_space(3))) void*)(lds + region_elems(KIND, NW) + 2 * NBIAS + (r * NW + w) * PIECE), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(lds + REGION + 2 * NBIAS + (r * NW + w) * PIECE), 16, 0, 0);
   }
   // (the ring's first two entries are requested BEHIND the prologue's register loads: a wait for those then leaves the DMA in flight)
   dma(0, 0);
@@ -399,16 +414,16 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   } else if constexpr (PIPE) {
-    bf16x8 pk[2] = {};               // bf16(pre-activation) of chunk j - 1: tile i, elements 4 t + r
-    bf16x8 avo[2] = {};              // PSKEW = 2: gelu of chunk j - 2
+    bf16x8 pk[TPW] = {};             // bf16(pre-activation) of chunk j - 1: tile i, elements 4 t + r
+    bf16x8 avo[TPW] = {};            // PSKEW = 2: gelu of chunk j - 2
     int slot = 0;
 
     // every iteration issues [DMA(J+2): PW] [S stores] (iterations without real stores send theirs out of range: dropped, but
     // counted), so the counted waits are those of the lockstep loop with NTOT entries
     auto top = [&](int J) {
-      if (J == 0) wait_vm<PW>();
-      else if (J == 1) wait_vm<PW + S>();
-      else if (J < NTOT - 1) wait_vm<PW + 2 * S>();
+      if (J == 0) WAIT_DMA(0);
+      else if (J == 1) WAIT_DMA(S);
+      else if (J < NTOT - 1) WAIT_DMA(2 * S);
       else wait_vm<2 * S>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -426,12 +441,12 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
           for (int ks = 0; ks < 6; ++ks) {
             const bf16x8 wp = *(const bf16x8*)(sb + (6 * u + ks) * PIECE);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a2[4 * J + u][i] = mfma16(wp, xf[i][ks], a2[4 * J + u][i]);
+            for (int i = 0; i < TPW; ++i) a2[4 * J + u][i] = mfma16(wp, xf[i][ks], a2[4 * J + u][i]);
           }
         {
           const u32x4v z = {0u, 0u, 0u, 0u};
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
+          for (int i = 0; i < TPW; ++i) {
             if (MODE >= 1) __builtin_amdgcn_raw_buffer_store_b128(z, r_act, 0xFFFFFF00u, 0, 0);
             if (MODE == 2) __builtin_amdgcn_raw_buffer_store_b128(z, r_dact, 0xFFFFFF00u, 0, 0);
           }
@@ -441,7 +456,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
       }
       // ---- + proj bias; norm2 in registers; xhat2 = the fc1 B fragments; then + fc2 bias (fc2 accumulates on top) ----
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < TPW; ++i) {
         float sum = 0.f;
 #pragma unroll
         for (int ot = 0; ot < 12; ++ot) {
@@ -481,29 +496,30 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
       top(j + J0);
       const bf16* sb = lds + slot * SLOT + lane * 8;
       const int cb = j < NCHUNK ? j : NCHUNK - 1;             // bias row of a real chunk (the products of the last PSKEW iterations are discarded)
-      f32x4 a1[2][2];
+      f32x4 a1[2][TPW];
       {
         const f32x4 ba = *(const f32x4*)(s_bias + cb * HC + 8 * lg), bb = *(const f32x4*)(s_bias + cb * HC + 8 * lg + 4);
-        a1[0][0] = ba; a1[0][1] = ba; a1[1][0] = bb; a1[1][1] = bb;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) { a1[0][i] = ba; a1[1][i] = bb; }
       }
       // ---- fc1 of chunk j (matrix pipe) ... ----
 #pragma unroll
       for (int ks = 0; ks < 6; ++ks) {
         const bf16x8 wa = *(const bf16x8*)(sb + ks * PIECE), wb = *(const bf16x8*)(sb + (6 + ks) * PIECE);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TPW; ++i) {
           a1[0][i] = mfma16(wa, xf[i][ks], a1[0][i]);
           a1[1][i] = mfma16(wb, xf[i][ks], a1[1][i]);
         }
       }
       // ---- ... with the GELU of chunk j - 1 in its shadow: table look-ups (a handful of integer operations and one 4-byte LDS
       // gather per element instead of ~20 fp32 operations with two transcendentals: the lockstep kernel is VALU-bound on those) ----
-      bf16x8 av[2], dv[2];
+      bf16x8 av[TPW], dv[TPW];
       {
-        unsigned t[2][8], ix[2][8];
+        unsigned t[TPW][8], ix[TPW][8];
         unsigned mx = 0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TPW; ++i) {
           const u32x4v pw = __builtin_bit_cast(u32x4v, pk[i]);
 #pragma unroll
           for (int d = 0; d < 4; ++d) {
@@ -519,7 +535,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
         }
         if (__builtin_amdgcn_ballot_w64(mx >= (unsigned)GT_N)) {          // rare: some lane holds an input outside the table
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < TPW; ++i)
 #pragma unroll
             for (int e = 0; e < 8; ++e)
               if (ix[i][e] >= (unsigned)GT_N) {
@@ -530,7 +546,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
               }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TPW; ++i) {
           u32x4v a, dd;
 #pragma unroll
           for (int d = 0; d < 4; ++d) {
@@ -552,7 +568,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
       if (MODE >= 1) {
         const bool real = j >= 1 && j <= NCHUNK;                // no such chunk: an offset beyond num_records (no wrap-around: absolute)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TPW; ++i) {
           const unsigned off = real ? soff[i] + (unsigned)(j - 1) * cblk : 0xFFFFFF00u;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, av[i]), r_act, off, 0, 0);
           if (MODE == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dv[i]), r_dact, off, 0, 0);
@@ -563,10 +579,10 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
       for (int ot = 0; ot < 12; ++ot) {
         const bf16x8 w2 = *(const bf16x8*)(sb + (12 + ot) * PIECE);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a2[ot][i] = mfma16(w2, PSKEW == 2 ? avo[i] : av[i], a2[ot][i]);
+        for (int i = 0; i < TPW; ++i) a2[ot][i] = mfma16(w2, PSKEW == 2 ? avo[i] : av[i], a2[ot][i]);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < TPW; ++i) {
         avo[i] = av[i];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -738,7 +754,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
   if constexpr (TAIL && KIND == 0) {
     // ---- a2 IS the updated residual stream (fp32, nothing staged through bf16): next LayerNorm in registers, 32- / 16-byte stores ----
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TPW; ++i) {
       float mean = 0.f, rs = 0.f;
       if (g.xhat) {
         float sum = 0.f;
@@ -790,26 +806,27 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
 #pragma unroll 1
       for (int e = 0; e < TQKV; ++e) {
         const int J = J0 + PENTRIES + e;
-        if (J < NTOT - 1) wait_vm<PW + 2 * S>(); else wait_vm<2 * S>();
+        if (J < NTOT - 1) WAIT_DMA(2 * S); else wait_vm<2 * S>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (J + 2 < NTOT) dma(J + 2, slot == 0 ? 2 : slot - 1);
         const bf16* sb = lds + slot * SLOT + lane * 8;
-        f32x4 acc[4][2];
+        f32x4 acc[4][TPW];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const f32x4 b = *(const f32x4*)(s_bias + HID + 2 * D + 64 * e + tail_col(u, 4 * lg));
-          acc[u][0] = b; acc[u][1] = b;
+#pragma unroll
+          for (int i = 0; i < TPW; ++i) acc[u][i] = b;
 #pragma unroll
           for (int ks = 0; ks < 6; ++ks) {
             const bf16x8 wq = *(const bf16x8*)(sb + (6 * u + ks) * PIECE);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acc[u][i] = mfma16(wq, xf[i][ks], acc[u][i]);
+            for (int i = 0; i < TPW; ++i) acc[u][i] = mfma16(wq, xf[i][ks], acc[u][i]);
           }
         }
         // stores: at least S per iteration (the counted waits assume them); rows beyond M are sent out of range
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TPW; ++i)
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             const unsigned off = mrow[i] < g.M ? (unsigned)mrow[i] * (3 * D * 2) + (64 * e + 32 * k + 8 * lg) * 2 : 0xFFFFFF00u;
@@ -821,6 +838,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
     }
     return;
   }
+  if constexpr (TPW == 2) {
   // ---- epilogue: bf16(out [+ b2]) staged in LDS (aliases the ring: every wave must have left the loop) ----
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -957,6 +975,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fused_kernel(const MlpArgs g) 
   for (int p = 0; p < 4; ++p) finish(p, xa[p], ha[p], ra[p]);
 #pragma unroll
   for (int p = 0; p < 4; ++p) finish(4 + p, xb[p], hb[p], rb[p]);
+  }
+#undef WAIT_DMA
 }
 
 // Weight stream of one block: chunk c (hidden units 32 c .. 32 c + 31) = 24 pieces of 64 x 16 bytes;
@@ -1217,9 +1237,26 @@ extern "C" int rovit_block_tail_fwd(const void* o, const void* wstream, const fl
   g.X = X; g.xhat = (bf16*)xhat_out; g.rstd = rstd_out; g.eps = eps; g.M = M; g.act_rows = act_rows; g.bq = bq_next; g.qkv = (bf16*)qkv_next;
   g.gelu_table = (const bf16*)wstream + (size_t)STREAM_ENTRIES * CH_ELEMS;
   g.wstream = (const bf16*)wstream + (size_t)(NCHUNK + PENTRIES) * CH_ELEMS;          // the block-tail image
-  const size_t lds = lds_bytes(0, 8) + 4 * D * sizeof(float) + GT_ENTRIES * 4;
   g.rpw = mlp_rpw(act_rows);
-  const dim3 grid((M + g.rpw - 1) / g.rpw), block(512);
+  const dim3 grid((M + g.rpw - 1) / g.rpw);
+#ifdef ROVIT_DEV        // measured slower (same box: 97.5 against 92.6 us training, 87.9 against 84.0 inference): developer library only
+  if (ROVIT_KNOB(ROVIT_KNOB_TAIL_WAVES, TAIL_WAVES_DEFAULT) == 16) {
+    // sixteen waves of one 16-row tile (four waves per SIMD): see the kernel's TPW note
+    const size_t lds = (size_t)NSLOT * slot_elems(0, 16) * sizeof(bf16) + (HID + D + 4 * D) * sizeof(float) + GT_ENTRIES * 4;
+#define LAUNCH_TAIL16(MD)                                                                                                        \
+  do {                                                                                                                           \
+    ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<0, MD, 16, false, true, true, 1>, lds), ROVIT_ERR_LAUNCH,    \
+                    "block_tail_fwd: cannot raise the LDS limit");                                                               \
+    hipLaunchKernelGGL((mlp_fused_kernel<0, MD, 16, false, true, true, 1>), grid, dim3(1024), lds, (hipStream_t)stream, g);      \
+  } while (0)
+    if (!act) LAUNCH_TAIL16(0); else if (!dact) LAUNCH_TAIL16(1); else LAUNCH_TAIL16(2);
+#undef LAUNCH_TAIL16
+    ROVIT_CHECK_LAUNCH("mlp_fused_kernel (block tail, 16 waves)");
+    return ROVIT_OK;
+  }
+#endif
+  const size_t lds = lds_bytes(0, 8) + 4 * D * sizeof(float) + GT_ENTRIES * 4;
+  const dim3 block(512);
 #define LAUNCH_TAIL(MD)                                                                                                          \
   do {                                                                                                                           \
     ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)mlp_fused_kernel<0, MD, 8, false, true, true>, lds), ROVIT_ERR_LAUNCH,        \

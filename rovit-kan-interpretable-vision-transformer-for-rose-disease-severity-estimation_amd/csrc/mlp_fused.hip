@@ -41,6 +41,10 @@
 #include <cstdlib>
 #include "common.h"
 
+// cache policy of the kept-activation stores (act, gelu'): 0 default, 2 = nt (written once, read by the backward 100+ MB of traffic later)
+#ifndef ROVIT_ACT_STORE_AUX
+#define ROVIT_ACT_STORE_AUX 0
+#endif
 #ifndef ROVIT_MLP_PIPE_HINTS
 #define ROVIT_MLP_PIPE_HINTS 0
 #endif
@@ -570,8 +574,8 @@ __global__ __launch_bounds__(NW * 64, TPW == 1 ? 4 : 2) void mlp_fused_kernel(co
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
           const unsigned off = real ? soff[i] + (unsigned)(j - 1) * cblk : 0xFFFFFF00u;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, av[i]), r_act, off, 0, 0);
-          if (MODE == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dv[i]), r_dact, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, av[i]), r_act, off, 0, ROVIT_ACT_STORE_AUX);
+          if (MODE == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dv[i]), r_dact, off, 0, ROVIT_ACT_STORE_AUX);
         }
       }
       // ---- fc2 of chunk j - PSKEW ----

@@ -38,6 +38,9 @@ KERNELS = [
     ('wgrad_kernel<192, 96, true, true, 2>', 0, 'patch_embed_wgrad'),
     ('kan_stack_mfma_kernel<4, 4', 0, 'kan_stack_mfma_kernel<4>'),
     ('kan_stack_mfma_kernel<18, 1', 0, 'kan_stack_mfma_kernel<18>'),
+    ('head_phase_fwd_kernel', 0, 'head_phase_fwd'),
+    ('head_phase_bwd_dx_kernel', 0, 'head_phase_bwd_per_sample'),
+    ('head_phase_dw_kernel', 0, 'head_phase_bwd_params'),
 ]
 SQ_PASSES = [
     ['SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_INSTS_VALU',

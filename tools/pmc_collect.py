@@ -28,11 +28,11 @@ KERNELS = [
     ('attn_bwd_kernel', 0, 'attention_bwd'),
     ('gemm_ws_kernel<6, 1, 64, 5>', 0, 'proj_fwd_resid_ln'),
     ('gemm_kdma_kernel<18, 6>', 0, 'qkv_dgrad_ln_bwd'),
-    ('mlp_fused_kernel<0, 2, 8, false, true, true>', 0, 'block_tail_train'),
-    ('mlp_fused_kernel<0, 0, 8, false, true, true>', 0, 'block_tail_inference'),
-    ('mlp_fused_kernel<0, 2, 8, false, true, false>', 0, 'mlp_fused_fwd_train'),
-    ('mlp_fused_kernel<0, 0, 8, false, true, false>', 0, 'mlp_fused_fwd_inference'),
-    ('mlp_fused_kernel<1, 1, 8, false, false, false>', 0, 'mlp_fused_bwd'),
+    ('mlp_fused_kernel<0, 2, 8, false, true, true,', 0, 'block_tail_train'),
+    ('mlp_fused_kernel<0, 0, 8, false, true, true,', 0, 'block_tail_inference'),
+    ('mlp_fused_kernel<0, 2, 8, false, true, false,', 0, 'mlp_fused_fwd_train'),
+    ('mlp_fused_kernel<0, 0, 8, false, true, false,', 0, 'mlp_fused_fwd_inference'),
+    ('mlp_fused_kernel<1, 1, 8, false, false, false,', 0, 'mlp_fused_bwd'),
     ('kan_fwd_kernel', 0, 'kan_fwd_kernel'),
     ('gemm_ws_kernel<12, 2, 32, 7>', 0, 'patch_embed_fwd'),
     ('wgrad_kernel<192, 96, true, true, 2>', 0, 'patch_embed_wgrad'),

@@ -400,10 +400,11 @@ def kan_roofline(dev, iters=30):
     res['c5_g32_b512_fwd_bwd'] = kan_fwd_bwd_roofline(dev, 32, 512, iters)
     res['c3_g5_b256_fwd_bwd'] = kan_fwd_bwd_roofline(dev, 5, 256, iters)
     res['head_phase_b256'] = head_phase_roofline(dev, 256, iters)
+    res['head_phase_c5_g32_b512'] = head_phase_roofline(dev, 512, iters, num_knots=32)
     return res
 
 
-def head_phase_roofline(dev, B, iters=30):
+def head_phase_roofline(dev, B, iters=30, num_knots=5):
     """What the training step runs at BASELINE.json configs[2] since round 4: the three heads AND the KAN stack as one forward launch and
     a two-launch backward (csrc/head_phase.hip), kernels only (direct C-ABI calls on preallocated buffers, dropout drawn in the kernel).
     Algorithmic bytes: every parameter once per launch (forward, per-sample backward) / read once and its gradient written once
@@ -413,7 +414,7 @@ def head_phase_roofline(dev, B, iters=30):
     from rovit_hip import native
     from rovit_hip.functions import HeadPhaseFn
     lib = native.load()
-    m = RoViTKAN(pretrained=False).to(dev).train()
+    m = RoViTKAN(pretrained=False, kan_num_knots=num_knots).to(dev).train()
     k = m.kan_module
     nl, hid = len(k.kan_layers), 128
     cfg = {'stage': 4, 'masks': None, 'drop_p': 0.3, 'seed': 1, 'offset': 0, 'kan_dims': list(k.layers_dims),
@@ -450,11 +451,11 @@ def head_phase_roofline(dev, B, iters=30):
     p_bytes = 4 * sum(p.numel() for p in hp + kp)
     io = 4 * B * (192 + 3 * hid + 4 + 3 + 1 + 1 + sum(k.layers_dims[1:]))
     alg = {'fwd': p_bytes + io, 'bwd_per_sample': p_bytes + 2 * io, 'bwd_params': 2 * p_bytes + 2 * io}
-    out = {'bound': 'hbm', 'kernel': 'head_phase_fwd_kernel<7> / head_phase_bwd_dx_kernel<7> / head_phase_dw_kernel: the three heads + the KAN stack '
-           '(192-64-16-1, num_knots 5), one workgroup per sample', 'batch': B, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'traffic': None}
+    out = {'bound': 'hbm', 'kernel': 'head_phase_fwd_kernel / head_phase_bwd_dx_kernel / head_phase_dw_kernel: the three heads + the KAN stack '
+           '(192-64-16-1, num_knots %d), one workgroup per sample' % num_knots, 'batch': B, 'num_knots': num_knots, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'traffic': None}
     for key, t in (('fwd', t_fwd), ('bwd_per_sample', t_dx), ('bwd_params', t_dw)):
         out[key + '_us'] = round(t * 1e3, 2)
-        out[key + '_traffic'] = _pmc_traffic('head_phase_' + key)
+        out[key + '_traffic'] = _pmc_traffic('head_phase_' + key) if num_knots == 5 and B == 256 else None
         out[key + '_algorithmic_bytes'] = float(alg[key])
         out[key + '_frac'] = round(alg[key] / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
     out['avg_us'] = round((t_fwd + t_dx + t_dw) * 1e3, 2)

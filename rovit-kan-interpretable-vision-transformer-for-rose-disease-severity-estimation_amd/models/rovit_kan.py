@@ -99,9 +99,9 @@ class RoViTKAN(nn.Module):
             return False
         d = k.layers_dims
         if not (k.degree == 3 and 1 <= len(k.kan_layers) <= 4 and d[0] == E and all(1 <= w <= 64 for w in d[1:]) and
-                all(l.knots.numel() - 4 in (7, 8) for l in k.kan_layers)):
-            # (num_basis 7 / 8 = num_knots 5 / 6: the dense-row kernels.  The kernels also cover other grids -- gathered weights -- but
-            # at BASELINE configs[4]'s num_knots 32, batch 512, the per-layer kernels are the faster ones: 54 against 82 us forward)
+                all(8 <= l.knots.numel() <= 64 for l in k.kan_layers)):
+            # (num_knots 5 / 6: dense basis rows; any other grid: one 16-byte load of the four live weights per (input, output) pair --
+            # BASELINE configs[4], num_knots 32 at batch 512: 50 us forward against 54 for the three per-layer launches, backward 144 against 126)
             return False
         if self.training and len({h.dropout.p for h in (c, o, u)}) != 1:
             return False

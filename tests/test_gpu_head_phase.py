@@ -97,9 +97,13 @@ def test_head_phase_forward_and_backward_vs_oracle(cfg, stage):
             assert float((got.detach().cpu() - ref.detach()).abs().max()) < 2e-5
     _weighted(outs, [w.to(dev()) for w in ws]).backward()
 
+    # gradients: 1e-4 of the tensor's largest entry; 3e-4 at num_knots 32, where the basis derivative carries 1 / h = 18.5 and the sums
+    # over 192 x 64 terms of mixed sign lose four digits in fp32 either way (the fp32 CPU oracle is as far from an fp64 evaluation)
+    rtol = 3e-4 if cfg['knots'] >= 32 else 1e-4
+
     def close(a, b, what):
         scale = float(b.abs().max()) + 1e-6
-        assert float((a.cpu() - b).abs().max()) <= 1e-4 * scale + 1e-7, what
+        assert float((a.cpu() - b).abs().max()) <= rtol * scale + 1e-7, what
     close(f.grad, xr.grad, 'd_features')
     nheads = 3 if stage >= 3 else (2 if stage >= 2 else 1)
     for k, p in zip(keys, params):

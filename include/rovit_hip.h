@@ -307,6 +307,14 @@ int rovit_attention_probs(const void* qkv, float* probs, int batch, int tokens, 
                           rovit_stream_t stream);
 int rovit_attention_bwd(const void* qkv, const void* out, const float* lse2, const void* dout, void* dqkv, int batch, int tokens,
                         int heads, int head_dim, float scale, rovit_stream_t stream);
+/* The same attention when ONLY THE CLASS TOKEN'S output is consumed -- the last block of the backbone, whose other rows nothing reads
+ * (timm VisionTransformer.forward_head takes x[:, 0], reached through models/backbone.py:23-25): 197 scores per (image, head) instead
+ * of 197 x 197.  Forward writes out[b, 0, :] and lse2[b, h, 0] only.  Backward takes the gradient of that row (dout[b, 0, :]; the other
+ * rows of dout are not read) and writes the WHOLE dqkv: dK, dV for every token, dQ for the class token, zeros in every other dQ row. */
+int rovit_attention_cls_fwd(const void* qkv, void* out, float* lse2, int batch, int tokens, int heads, int head_dim, float scale,
+                            rovit_stream_t stream);
+int rovit_attention_cls_bwd(const void* qkv, const void* out, const float* lse2, const void* dout, void* dqkv, int batch, int tokens,
+                            int heads, int head_dim, float scale, rovit_stream_t stream);
 int rovit_layernorm_fwd(const float* x, void* xhat, float* rstd, int rows, int dim, float eps, rovit_stream_t stream);
 int rovit_layernorm_bwd(const void* dxhat, const void* xhat, const float* rstd, float* dX, void* dXb, int rows, int dim,
                         rovit_stream_t stream);

@@ -834,6 +834,172 @@ extern "C" int rovit_attention_probs(const void* qkv, float* probs, int batch, i
   return ROVIT_OK;
 }
 
+namespace {
+// ---- the LAST block's attention: only the class token's query is ever consumed (round 4) -------------------------------------------
+// Behind the last block's attention the model reads token 0 only (final norm + heads), and proj / MLP are row-wise: rovit_vit_forward
+// already runs that half on the B class-token rows (round 1).  The attention itself is row-wise in the QUERY: the class token's output
+// needs its own query and every key / value, nothing else -- so the last block's forward is 197 scores per (image, head) instead of
+// 197 x 197, and its backward a rank-one update (dV = p (x) dO, dK = scale dS (x) q, dQ_cls = scale sum_k dS_k K_k; every other dQ row
+// is exactly zero).  Exact dead-code elimination: 24 -> ~10 us forward, 44 -> ~20 us backward, both now bound by reading K / V once
+// (and writing dqkv once).  fp32 FMAs on the bf16 operands (no matrix work worth the name: 50 KFLOP per item); the probabilities stay
+// fp32 (the full kernel rounds them to bf16 for the P V product).  One wave per (image, head), 8 lanes per key row (16 bytes each: 128-byte
+// runs), 8 keys per step.
+constexpr int CLS_STEPS = TP / 8;          // 28 steps of 8 keys
+__global__ __launch_bounds__(256) void attn_cls_fwd_kernel(const AttnArgs a, int n_items) {
+  const int lane = threadIdx.x & 63;
+  const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bh >= n_items) return;                                   // whole wave; no barrier in this kernel
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int ld = 3 * a.H * HD;
+  const bf16* base = a.qkv + (size_t)b * a.T * ld + h * HD;
+  const int part = lane & 7, ks = lane >> 3;
+  const float c2 = a.scale * LOG2E;
+  float q[8];
+  {
+    const bf16x8 qv = *(const bf16x8*)(base + part * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[e] = (float)qv[e] * c2;
+  }
+  float sc[CLS_STEPS];
+  float m = -INFINITY;
+  // every K and V row of the item is requested up front (one wave per SIMD: 224 registers of operands are affordable): the kernel is
+  // one round trip to memory, not two with the softmax between them
+  bf16x8 kreg[CLS_STEPS], vreg[CLS_STEPS];
+#pragma unroll
+  for (int it = 0; it < CLS_STEPS; ++it) {
+    const int key = 8 * it + ks, kc = key < a.T ? key : a.T - 1;
+    kreg[it] = *(const bf16x8*)(base + a.H * HD + (size_t)kc * ld + part * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < CLS_STEPS; ++it) {
+    const int key = 8 * it + ks, kc = key < a.T ? key : a.T - 1;       // padded keys carry p = 0
+    vreg[it] = *(const bf16x8*)(base + 2 * a.H * HD + (size_t)kc * ld + part * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < CLS_STEPS; ++it) {
+    const int key = 8 * it + ks;
+    const bf16x8 kv = kreg[it];
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d = fmaf(q[e], (float)kv[e], d);
+    d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+    sc[it] = key < a.T ? d : -INFINITY;
+    m = fmaxf(m, sc[it]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 8)); m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+  float l = 0.f;
+#pragma unroll
+  for (int it = 0; it < CLS_STEPS; ++it) { sc[it] = __builtin_amdgcn_exp2f(sc[it] - m); l += sc[it]; }
+  l += __shfl_xor(l, 8); l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+  if (lane == 0 && a.lse2) a.lse2[((size_t)b * a.H + h) * a.T] = m + log2f(l);
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < CLS_STEPS; ++it) {
+    const bf16x8 vv = vreg[it];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = fmaf(sc[it], (float)vv[e], o[e]);
+  }
+  const float inv_l = 1.f / l;
+  bf16x8 ov;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = o[e];
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    ov[e] = (bf16)(v * inv_l);
+  }
+  if (ks == 0) *(bf16x8*)(a.out + (size_t)b * a.T * (a.H * HD) + h * HD + part * 8) = ov;
+}
+
+__global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const AttnArgs a, int n_items) {
+  const int lane = threadIdx.x & 63;
+  const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bh >= n_items) return;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int ld = 3 * a.H * HD, ldo = a.H * HD;
+  const bf16* base = a.qkv + (size_t)b * a.T * ld + h * HD;
+  bf16* dbase = a.dqkv + (size_t)b * a.T * ld + h * HD;
+  const int part = lane & 7, ks = lane >> 3;
+  const float c2 = a.scale * LOG2E;
+  float q[8], g[8];
+  float delta = 0.f;
+  {
+    const bf16x8 qv = *(const bf16x8*)(base + part * 8);
+    const bf16x8 gv = *(const bf16x8*)(a.dout + (size_t)b * a.T * ldo + h * HD + part * 8);
+    const bf16x8 ov = *(const bf16x8*)(a.out + (size_t)b * a.T * ldo + h * HD + part * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { q[e] = (float)qv[e]; g[e] = (float)gv[e]; delta = fmaf(g[e], (float)ov[e], delta); }
+  }
+  delta += __shfl_xor(delta, 1); delta += __shfl_xor(delta, 2); delta += __shfl_xor(delta, 4);
+  const float lse = a.lse2[((size_t)b * a.H + h) * a.T];
+  float dq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bf16x8 zero8 = {};
+#pragma unroll 4
+  for (int it = 0; it < CLS_STEPS; ++it) {
+    const int key = 8 * it + ks, kc = key < a.T ? key : a.T - 1;
+    const bf16x8 kv = *(const bf16x8*)(base + a.H * HD + (size_t)kc * ld + part * 8);
+    const bf16x8 vv = *(const bf16x8*)(base + 2 * a.H * HD + (size_t)kc * ld + part * 8);
+    float sd = 0.f, dp = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sd = fmaf(q[e], (float)kv[e], sd); dp = fmaf(g[e], (float)vv[e], dp); }
+    sd += __shfl_xor(sd, 1); sd += __shfl_xor(sd, 2); sd += __shfl_xor(sd, 4);
+    dp += __shfl_xor(dp, 1); dp += __shfl_xor(dp, 2); dp += __shfl_xor(dp, 4);
+    const float p = key < a.T ? __builtin_amdgcn_exp2f(fmaf(sd, c2, -lse)) : 0.f;
+    const float ds = p * (dp - delta);
+    bf16x8 dkv, dvv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dq[e] = fmaf(ds, (float)kv[e], dq[e]);
+      dkv[e] = (bf16)(a.scale * ds * q[e]);
+      dvv[e] = (bf16)(p * g[e]);
+    }
+    if (key < a.T) {
+      bf16* row = dbase + (size_t)key * ld + part * 8;
+      *(bf16x8*)(row + a.H * HD) = dkv;
+      *(bf16x8*)(row + 2 * a.H * HD) = dvv;
+      if (key > 0) *(bf16x8*)row = zero8;          // every query but the class token's: its gradient is exactly zero (the buffer is reused)
+    }
+  }
+  bf16x8 dqv;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = dq[e];
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    dqv[e] = (bf16)(a.scale * v);
+  }
+  if (ks == 0) *(bf16x8*)(dbase + part * 8) = dqv;
+}
+
+}  // namespace
+
+// the last block's attention when only the class token's row of `out` is consumed / of `dout` carries gradient (include/rovit_hip.h).
+// Writes out[b, 0, :] and lse2[b, h, 0] only; the backward writes the whole dqkv (dQ rows 1.. are zeros).
+extern "C" int rovit_attention_cls_fwd(const void* qkv, void* out, float* lse2, int batch, int tokens, int heads, int head_dim, float scale,
+                                       rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(qkv && out, ROVIT_ERR_NULL, "attention_cls_fwd: null pointer");
+  ROVIT_CHECK_ARG(batch > 0 && tokens > 0 && tokens <= TP && head_dim == HD && heads > 0, ROVIT_ERR_SHAPE, "attention_cls_fwd: unsupported shape");
+  ROVIT_CHECK_ARG(rovit_aligned16(qkv) && rovit_aligned16(out), ROVIT_ERR_ALIGN, "attention_cls_fwd: alignment");
+  AttnArgs a{};
+  a.qkv = (const bf16*)qkv; a.out = (bf16*)out; a.lse2 = lse2; a.T = tokens; a.H = heads; a.scale = scale;
+  const int items = batch * heads;
+  hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, items);
+  ROVIT_CHECK_LAUNCH("attn_cls_fwd_kernel");
+  return ROVIT_OK;
+}
+extern "C" int rovit_attention_cls_bwd(const void* qkv, const void* out, const float* lse2, const void* dout, void* dqkv, int batch, int tokens,
+                                       int heads, int head_dim, float scale, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(qkv && out && lse2 && dout && dqkv, ROVIT_ERR_NULL, "attention_cls_bwd: null pointer");
+  ROVIT_CHECK_ARG(batch > 0 && tokens > 0 && tokens <= TP && head_dim == HD && heads > 0, ROVIT_ERR_SHAPE, "attention_cls_bwd: unsupported shape");
+  ROVIT_CHECK_ARG(rovit_aligned16(qkv) && rovit_aligned16(out) && rovit_aligned16(dout) && rovit_aligned16(dqkv), ROVIT_ERR_ALIGN,
+                  "attention_cls_bwd: alignment");
+  AttnArgs a{};
+  a.qkv = (const bf16*)qkv; a.out = (bf16*)const_cast<void*>(out); a.lse2 = (float*)lse2; a.T = tokens; a.H = heads; a.scale = scale;
+  a.dout = (const bf16*)dout; a.dqkv = (bf16*)dqkv; a.dout_rows = 1;
+  const int items = batch * heads;
+  hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, items);
+  ROVIT_CHECK_LAUNCH("attn_cls_bwd_kernel");
+  return ROVIT_OK;
+}
+
 extern "C" int rovit_attention_fwd(const void* qkv, void* out, float* lse2, int batch, int tokens, int heads, int head_dim,
                                    float scale, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(qkv && out, ROVIT_ERR_NULL, "attention_fwd: null pointer");

@@ -65,7 +65,9 @@ constexpr int PIECE = 512;                    // bf16 elements of a 1 KB piece (
 constexpr int CH_PIECES = 24;                 // 12 first-GEMM fragments (2 tiles x 6 k-steps) + 12 second-GEMM fragments (12 output tiles)
 constexpr int CH_ELEMS = CH_PIECES * PIECE;   // 24 KB of weights per chunk
 constexpr int NSLOT = 3;
+#ifdef ROVIT_DEV
 constexpr int TAIL_WAVES_DEFAULT = 8;     // waves per workgroup of the forward block tail (16: one row tile per wave)
+#endif
 // pipelined forward: ring entry j carries the fc2 fragments of hidden chunk j - PSKEW next to the fc1 fragments of chunk j.
 // PSKEW = 2: iteration j issues fc1 of chunk j, the GELU look-ups of chunk j - 1 and fc2 of chunk j - 2 -- three mutually
 // independent streams of work (matrix, vector + LDS gather, matrix); 1: fc2 of chunk j - 1 behind its own GELU.

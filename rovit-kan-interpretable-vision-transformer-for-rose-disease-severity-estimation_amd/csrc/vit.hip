@@ -321,8 +321,15 @@ int vit_forward_impl(const float* images, const float* const* params, const void
     qkv_done = false;
     EACH_HALF {
       const Half& h = halves[hh];
-      RUN(rovit_attention_fwd(ROWS(s + L.qkv, 3 * D, 2), ROWS(s + L.o, D, 2), (float*)(s + L.lse) + (size_t)h.b0 * H * T, h.nb, T, H, D / H,
-                              0.125f, h.st));
+      // the last block: only the class token's attention output is consumed (the half behind it runs on those rows alone), and a query's
+      // output needs no other query -- 197 scores per (image, head) instead of 197 x 197 (taps want every token's output: full kernel)
+      if (cls_only && !attn_taps && !prob_taps) {
+        RUN(rovit_attention_cls_fwd(ROWS(s + L.qkv, 3 * D, 2), ROWS(s + L.o, D, 2), (float*)(s + L.lse) + (size_t)h.b0 * H * T, h.nb, T, H, D / H,
+                                    0.125f, h.st));
+      } else {
+        RUN(rovit_attention_fwd(ROWS(s + L.qkv, 3 * D, 2), ROWS(s + L.o, D, 2), (float*)(s + L.lse) + (size_t)h.b0 * H * T, h.nb, T, H, D / H,
+                                0.125f, h.st));
+      }
     }
     // explainability tap: the attention module's output (proj(attention) + bias, before the residual add) for
     // every token of block i -- what a forward hook on `blocks[i].attn` sees (reference models/backbone.py:37-62)
@@ -556,7 +563,8 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
             {(const float*)(ws + L.slab_proj), sc, D, D, nullptr, nullptr, nullptr, bg[B_PROJW], bg[B_PROJB], nullptr, nullptr, nullptr}};
         RUN(rovit_wgrad_reduce_batch(rd, 3, sB));
       }
-      RUN(rovit_attention_bwd_rows(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, 1, dq, batch, T, H, D / H, 0.125f, stream));
+      // only the class token's row of dO carries gradient: a rank-one backward (attention.hip), which also zeroes the other queries' dQ rows
+      RUN(rovit_attention_cls_bwd(s + L.qkv, s + L.o, (const float*)(s + L.lse), ws + L.dO, dq, batch, T, H, D / H, 0.125f, stream));
       RUN(rovit_gemm_ln_bwd_cls(dq, 3 * D, q + P.wqkvT, 3 * D, M, 3 * D, s + L.xhat1, (const float*)(s + L.rstd1), xmc, T, xout, stream));
       // the (full-size) qkv weight gradient of this block goes the way of every other block's: as `pending`, into the next block's
       // merged launch on the weight-gradient stream (or the flush behind the loop) instead of 50 us of serial work here

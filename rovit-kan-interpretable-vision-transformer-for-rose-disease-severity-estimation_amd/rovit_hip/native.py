@@ -74,6 +74,8 @@ SIGNATURES = {
     'rovit_wgrad_reduce': (_i, [_vp, _i, _i, _i] + [_vp] * 8 + [_vp]),
     'rovit_attention_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     'rovit_attention_bwd': (_i, [_vp] * 5 + [_i] * 4 + [_f, _vp]),
+    'rovit_attention_cls_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    'rovit_attention_cls_bwd': (_i, [_vp] * 5 + [_i] * 4 + [_f, _vp]),
     'rovit_layernorm_fwd': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     'rovit_layernorm_bwd': (_i, [_vp] * 5 + [_i, _i, _vp]),
     'rovit_im2col': (_i, [_vp, _vp, _i, _vp]),

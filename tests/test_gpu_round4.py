@@ -193,3 +193,56 @@ def test_pos_grad_from_bf16_rows_and_cls_norm_bwd_without_zero_fill():
         res.append((dX.view(B, T, 192), dXo.view(B, T, 192)))
     assert torch.equal(res[0][0][:, 0], res[1][0][:, 0]) and torch.equal(res[0][1][:, 0], res[1][1][:, 0])
     assert bool((res[0][0][:, 1:] == 0).all()) and bool((res[1][0][:, 1:] == 3.0).all()) and bool((res[1][1][:, 1:].float() == 3.0).all())
+
+
+@pytest.mark.parametrize('B,T', [(5, 197), (3, 64), (2, 208), (1, 9)])
+def test_class_token_attention_equals_the_full_kernels_row_and_a_torch_reference(B, T):
+    """The last block's attention (rovit_attention_cls_fwd / _bwd): only the class token's output is consumed, so only its query is
+    evaluated.  Against fp32 torch on the same bf16 operands: 2e-2 of the bf16 output scale forward (the full kernel's own distance),
+    and backward gradients within 2e-2 relative; against the full kernels' class-token row / a dout that is zero elsewhere: the same
+    bound (the full kernel rounds the probabilities to bf16 for its matrix products, this one keeps them in fp32).  Every dQ row but
+    the class token's must be EXACT zeros (the buffer is reused across blocks: poisoned first), whatever tokens."""
+    from rovit_hip import native
+    H, HD = 3, 64
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    qkv = (torch.randn(B * T, 3 * H * HD, generator=g) * 1.5).to(dev()).to(torch.bfloat16)
+    dout = torch.zeros(B * T, H * HD, device=dev(), dtype=torch.bfloat16)
+    dcls = torch.randn(B, H * HD, generator=g).to(dev()).to(torch.bfloat16)
+    dout.view(B, T, H * HD)[:, 0] = dcls
+    sp = native.stream_ptr()
+    # fp32 reference on the bf16 values
+    x = qkv.float().view(B, T, 3, H, HD)
+    q, k, v = (x[:, :, i].permute(0, 2, 1, 3).clone().requires_grad_(True) for i in range(3))        # (B,H,T,HD)
+    s = (q[:, :, :1] @ k.transpose(-1, -2)) * 0.125
+    o_ref = torch.softmax(s, dim=-1) @ v                                                                # (B,H,1,HD)
+    (o_ref * dcls.float().view(B, 1, H, HD).permute(0, 2, 1, 3)).sum().backward()
+    # full kernels
+    out_full = torch.empty(B * T, H * HD, device=dev(), dtype=torch.bfloat16)
+    lse_full = torch.empty(B, H, T, device=dev())
+    native.call('rovit_attention_fwd', native.ptr(qkv), native.ptr(out_full), native.ptr(lse_full), B, T, H, HD, 0.125, sp)
+    dq_full = torch.empty_like(qkv)
+    native.call('rovit_attention_bwd', native.ptr(qkv), native.ptr(out_full), native.ptr(lse_full), native.ptr(dout), native.ptr(dq_full),
+                B, T, H, HD, 0.125, sp)
+    # class-token kernels (outputs poisoned first)
+    out = torch.full((B * T, H * HD), float('nan'), device=dev(), dtype=torch.bfloat16)
+    lse = torch.full((B, H, T), float('nan'), device=dev())
+    native.call('rovit_attention_cls_fwd', native.ptr(qkv), native.ptr(out), native.ptr(lse), B, T, H, HD, 0.125, sp)
+    o = out.view(B, T, H, HD)[:, 0].float()
+    ref = o_ref[:, :, 0].detach().float()
+    scale = float(ref.abs().max())
+    assert float((o - ref).abs().max()) < 1e-2 * scale + 1e-2
+    assert float((o - out_full.view(B, T, H, HD)[:, 0].float()).abs().max()) < 2e-2 * scale + 1e-2
+    assert float((lse[:, :, 0] - lse_full[:, :, 0]).abs().max()) < 2e-2
+    assert bool(torch.isnan(out.view(B, T, H * HD)[:, 1:].float()).all()) or T == 1        # nothing but the class token's row is written
+    dqkv = torch.full_like(qkv, float('nan'))
+    native.call('rovit_attention_cls_bwd', native.ptr(qkv), native.ptr(out), native.ptr(lse), native.ptr(dout), native.ptr(dqkv), B, T, H, HD,
+                0.125, sp)
+    d = dqkv.float().view(B, T, 3, H, HD)
+    assert not bool(torch.isnan(d).any())
+    assert bool((d[:, 1:, 0] == 0).all())                                  # exact zeros in every other query's gradient
+    for i, ref_g in enumerate((q.grad, k.grad, v.grad)):
+        got = d[:, :, i].permute(0, 2, 1, 3)
+        sc = float(ref_g.abs().max())
+        assert float((got - ref_g).abs().max()) < 2e-2 * sc + 1e-3, 'qkv'[i]
+        full = dq_full.float().view(B, T, 3, H, HD)[:, :, i].permute(0, 2, 1, 3)
+        assert float((got - full).abs().max()) < 3e-2 * sc + 1e-3, 'qkv'[i]

@@ -321,6 +321,12 @@ int vit_forward_impl(const float* images, const float* const* params, const void
     qkv_done = false;
     EACH_HALF {
       const Half& h = halves[hh];
+      // (developer knob 19: the second half-batch starts its first attention behind the first half's, so that one half's attention runs
+      // beside the other half's block tail for the rest of the forward instead of both halves moving in phase)
+      if (ROVIT_KNOB(ROVIT_KNOB_FWD_STAGGER, 0) && ss && i == 0 && hh == 1 && !hand_over(ss, (hipStream_t)stream, ss->stream)) {
+        rovit_set_error("vit_forward: event hand-over failed");
+        return ROVIT_ERR_LAUNCH;
+      }
       // the last block: only the class token's attention output is consumed (the half behind it runs on those rows alone), and a query's
       // output needs no other query -- 197 scores per (image, head) instead of 197 x 197 (taps want every token's output: full kernel)
       if (cls_only && !attn_taps && !prob_taps) {

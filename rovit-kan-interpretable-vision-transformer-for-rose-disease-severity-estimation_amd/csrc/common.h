@@ -207,6 +207,7 @@ int rovit_layernorm_fwd_rows(const float* x, void* xhat, float* rstd, int rows, 
 int rovit_layernorm_bwd_rows(const void* dxhat, const void* xhat, const float* rstd, float* dX, void* dXb, int rows, int row_step,
                              rovit_stream_t stream);
 
+int rovit_cls_norm_affine_grad(const float* dfeat, const float* xhat, float* dgamma, float* dbeta, int batch, rovit_stream_t stream);
 // attention backward whose dout carries gradient on the first `dout_rows` rows of every image only (the last block: the class token's)
 int rovit_attention_bwd_rows(const void* qkv, const void* out, const float* lse2, const void* dout, int dout_rows, void* dqkv, int batch,
                              int tokens, int heads, int head_dim, float scale, rovit_stream_t stream);

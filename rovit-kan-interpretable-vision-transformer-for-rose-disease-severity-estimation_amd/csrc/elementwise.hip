@@ -413,6 +413,15 @@ extern "C" int rovit_cls_norm_bwd(const float* dfeat, const float* xhat, const f
   return ROVIT_OK;
 }
 
+// (internal, common.h) dgamma / dbeta of the final norm alone: sample sums nobody on the dgrad chain waits for -- rovit_vit_backward runs
+// them on its weight-gradient stream
+int rovit_cls_norm_affine_grad(const float* dfeat, const float* xhat, float* dgamma, float* dbeta, int batch, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(dfeat && xhat && dgamma && dbeta, ROVIT_ERR_NULL, "cls_norm_affine_grad: null pointer");
+  hipLaunchKernelGGL(cls_ln_affine_grad_kernel, dim3((D + 63) / 64), dim3(1024), 0, (hipStream_t)stream, dfeat, xhat, dgamma, dbeta, batch);
+  ROVIT_CHECK_LAUNCH("cls_ln_affine_grad_kernel");
+  return ROVIT_OK;
+}
+
 // exactly one of dX (fp32) / dXb (bf16, round 4) is the gradient w.r.t. the embedded tokens (B*tokens, 192)
 extern "C" int rovit_pos_grad(const float* dX, const void* dXb, float* dpos, float* dcls, int batch, int tokens, rovit_stream_t stream) {
   ROVIT_CHECK_ARG((dX != nullptr) != (dXb != nullptr) && dpos && dcls, ROVIT_ERR_NULL, "pos_grad: pass exactly one of dX / dXb, and the outputs");

@@ -457,8 +457,10 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
   auto x0v = [&](int i) { return ws + L.x0[(i + 3) % 3]; };
   if (first_block == depth - 1) {
     ROVIT_CHECK_ARG(d_features, ROVIT_ERR_NULL, "vit_backward: null d_features");
+    // (the final norm's dgamma / dbeta -- sample sums off the dgrad chain -- go to the weight-gradient stream below when there is one)
+    const bool affine_on_b = two_streams_enabled() && side_stream() != nullptr;
     RUN(rovit_cls_norm_bwd(d_features, (const float*)(ws + L.xhat_cls), (const float*)(ws + L.rstd_cls), params[P_NORM_W], dX,
-                           x0v(depth - 1), grads[P_NORM_W], grads[P_NORM_B], batch, T, 0, stream));
+                           x0v(depth - 1), affine_on_b ? nullptr : grads[P_NORM_W], affine_on_b ? nullptr : grads[P_NORM_B], batch, T, 0, stream));
   }
   // Two-stream schedule (see SideStream above).  Per block i (p = i & 1), stream A runs the dgrad chain
   //   A1 + A2 MLP half (fc2 dgrad * gelu' -> dpre[p]; fc1 dgrad + norm2 bwd -> dX, x1[p]): one launch from batch 173, else two
@@ -554,6 +556,7 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
       RUN(rovit_gemm_nt(xmc, D * rs, q + P.wprojT, D, Mr, D, D, nullptr, EPI_BF16, ws + L.dO, D * rs, nullptr, nullptr, 0, nullptr, 0, nullptr,
                         0, stream));
       if (ss && !hand_over(ss, sA, sB)) EVFAIL("event hand-over");
+      if (ss) RUN(rovit_cls_norm_affine_grad(d_features, (const float*)(ws + L.xhat_cls), grads[P_NORM_W], grads[P_NORM_B], batch, sB));
       {
         const float* const* bpp = params + P_BLOCK0 + B_COUNT * i;
         float* const* bg = grads + P_BLOCK0 + B_COUNT * i;

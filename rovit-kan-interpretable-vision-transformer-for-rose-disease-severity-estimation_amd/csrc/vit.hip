@@ -296,6 +296,7 @@ int vit_forward_impl(const float* images, const float* const* params, const void
   }
   struct BudgetReset { bool on; ~BudgetReset() { if (on) rovit_set_cu_budget(256); } } budget_reset{ss != nullptr};
 #define EACH_HALF for (int hh = 0; hh < nh; ++hh)
+  const bool cls_fused = !attn_taps && !prob_taps;      // the last block's class-token rows: one launch (cls_tail.hip)
   bool qkv_done = false;              // the previous block's tail launch has already written this block's qkv projection
   for (int i = 0; i < depth; ++i) {
     const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
@@ -345,6 +346,19 @@ int vit_forward_impl(const float* images, const float* const* params, const void
     // ... and, separately, the softmax probabilities (B,3,197,197) the reference's rollout code means to collect
     // (explainability/attention_maps.py:18-105)
     if (prob_taps && prob_taps[i]) RUN(rovit_attention_probs(s + L.qkv, prob_taps[i], batch, T, H, D / H, 0.125f, stream));
+    // The last block: its post-attention half AND the final norm on the class-token rows in ONE launch (cls_tail.hip; six launches before).
+    // (Taps want the attention module's output for every token: the launch-by-launch path below.)
+    if (cls_only && cls_fused) {
+      EACH_HALF {
+        const Half& h = halves[hh];
+        RUN(rovit_cls_tail_fwd(ROWS(s + L.o, D, 2), X + (size_t)h.b0 * T * D, q + P.wproj, bp[B_PROJB], q + P.wfc1, (const float*)(q + P.bfc1),
+                               q + P.wfc2, bp[B_FC2B], params[P_NORM_W], params[P_NORM_B], training ? ROWS(s + L.xhat2, D, 2) : nullptr,
+                               training ? (float*)ROWS(s + L.rstd2, 1, 4) : nullptr, training ? ROWS(s + L.act, MLP, 2) : nullptr,
+                               training ? ROWS(s + L.dact, MLP, 2) : nullptr, features + (size_t)h.b0 * D,
+                               (float*)(ws + L.xhat_cls) + (size_t)h.b0 * D, (float*)(ws + L.rstd_cls) + h.b0, h.nb, T, eps, h.st));
+      }
+      continue;
+    }
     // Everything behind the attention in ONE launch ("block tail", mlp_fused.hip: proj + residual + norm2 + MLP + residual + next
     // norm1 + the NEXT block's qkv projection; the residual stream stays in registers between the halves).
     if (!cls_only && mlp_one_launch(mlp_path, (long)batch * T)) {
@@ -398,8 +412,9 @@ int vit_forward_impl(const float* images, const float* const* params, const void
   }
 #undef EACH_HALF
   if (ss && !hand_over(ss, ss->stream, (hipStream_t)stream)) { rovit_set_error("vit_forward: event hand-over failed"); return ROVIT_ERR_LAUNCH; }
-  RUN(rovit_cls_norm_fwd(X, params[P_NORM_W], params[P_NORM_B], features, (float*)(ws + L.xhat_cls), (float*)(ws + L.rstd_cls), batch,
-                         T, eps, stream));
+  if (!cls_fused)
+    RUN(rovit_cls_norm_fwd(X, params[P_NORM_W], params[P_NORM_B], features, (float*)(ws + L.xhat_cls), (float*)(ws + L.rstd_cls), batch,
+                           T, eps, stream));
   return ROVIT_OK;
 }
 }  // namespace

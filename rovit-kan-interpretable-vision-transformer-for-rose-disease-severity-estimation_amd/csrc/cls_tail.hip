@@ -119,6 +119,139 @@ __global__ __launch_bounds__(1024) void cls_tail_fwd_kernel(const ClsTailArgs a)
   }
 }
 
+// ---- backward of the same chain, one workgroup per row: final-norm backward -> fc2 dgrad x gelu' -> fc1 dgrad -> norm2 backward -> proj dgrad.
+// Mirrors the launches it replaces (rovit_cls_norm_bwd, rovit_gemm_nt EPI_MUL / EPI_BF16, rovit_layernorm_bwd_rows): the residual gradient
+// is rounded to bf16 where a GEMM reads it as its operand, dgrad results are rounded to bf16 where the GEMM path stages them, the norm
+// backward sums in fp32.  The dgrad products contract over the ROWS of the row-major forward weight images (no transposed image needed):
+// thread = (eight consecutive output columns, row slice), partial sums meet in LDS in slice order.
+struct ClsTailBwdArgs {
+  const float* dfeat; const float* xhat_cls; const float* rstd_cls; const float* gamma;      // final norm
+  const bf16* wfc2; const bf16* wfc1; const bf16* wproj;                                      // (192,768), (768,192), (192,192)
+  const bf16* dact; long act_ld;         // gelu' rows
+  const bf16* xhat2; long xh_ld; const float* rstd2; long rs_ld;
+  bf16* xin; bf16* dpre; bf16* xmid; bf16* dO; long row_ld192; long row_ld768;               // outputs, row b at b * row_ld (elements)
+};
+
+__global__ __launch_bounds__(1024) void cls_tail_bwd_kernel(const ClsTailBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_part[32 * D];          // [8][768] or [32][192] partial sums
+  __shared__ __attribute__((aligned(16))) float s_dx[D], s_v[D], s_dp[MLP];
+  const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63;
+  // final-norm backward (one wave): dx0 = rstd (g - mean(g) - xhat mean(g xhat)), g = dfeat * gamma
+  if (tid < 64) {
+    float g[3], h[3];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int c = lane + 64 * u;
+      g[u] = a.dfeat[(size_t)b * D + c] * a.gamma[c];
+      h[u] = a.xhat_cls[(size_t)b * D + c];
+      s1 += g[u]; s2 += g[u] * h[u];
+    }
+    const float c1 = wave_sum64(s1) * (1.f / D), c2 = wave_sum64(s2) * (1.f / D), r = a.rstd_cls[b];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int c = lane + 64 * u;
+      const float dx = r * (g[u] - c1 - h[u] * c2);
+      const bf16 xb = (bf16)dx;
+      s_dx[c] = dx;                          // the fp32 residual gradient (norm2's backward adds onto it)
+      s_v[c] = (float)xb;                    // its bf16 rounding: the fc2 dgrad's operand and the fc2 weight gradient's dY
+      a.xin[(size_t)b * a.row_ld192 + c] = xb;
+    }
+  }
+  __syncthreads();
+  // fc2 dgrad: t[k] = sum_n xin[n] W2[n][k]; thread = (8 consecutive k, one of 8 slices of 24 rows n)
+  if (tid < 768) {
+    const int kc = tid % 96, sl = tid / 96;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 6
+    for (int n = 24 * sl; n < 24 * sl + 24; ++n) {
+      const bf16x8 w = *(const bf16x8*)(a.wfc2 + (size_t)n * MLP + 8 * kc);
+      const float x = s_v[n];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(x, (float)w[e], acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_part[sl * MLP + 8 * kc + e] = acc[e];
+  }
+  __syncthreads();
+  if (tid < MLP) {
+    float t = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) t += s_part[sl * MLP + tid];
+    const bf16 dp = (bf16)((float)(bf16)t * (float)a.dact[(size_t)b * a.act_ld + tid]);      // x gelu', staged in bf16 like EPI_MUL
+    s_dp[tid] = (float)dp;
+    a.dpre[(size_t)b * a.row_ld768 + tid] = dp;
+  }
+  __syncthreads();
+  // fc1 dgrad: dxhat2[i] = sum_k dpre[k] W1f[k][i]; thread = (8 consecutive i, one of 32 slices of 24 rows k)
+  if (tid < 768) {
+    const int ic = tid % 24, sl = tid / 24;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 6
+    for (int k = 24 * sl; k < 24 * sl + 24; ++k) {
+      const bf16x8 w = *(const bf16x8*)(a.wfc1 + (size_t)k * D + 8 * ic);
+      const float x = s_dp[k];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(x, (float)w[e], acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_part[sl * D + 8 * ic + e] = acc[e];
+  }
+  __syncthreads();
+  if (tid < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 32; ++sl) t += s_part[sl * D + tid];
+    s_v[tid] = (float)(bf16)t;               // dxhat2, staged in bf16 like EPI_BF16
+  }
+  __syncthreads();
+  // norm2 backward (one wave): dx1 = dx0 + rstd2 (v - mean(v) - xhat2 mean(v xhat2)); its bf16 rounding = the mid-block gradient
+  if (tid < 64) {
+    float v[3], h[3];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int c = lane + 64 * u;
+      v[u] = s_v[c];
+      h[u] = (float)a.xhat2[(size_t)b * a.xh_ld + c];
+      s1 += v[u]; s2 += v[u] * h[u];
+    }
+    const float c1 = wave_sum64(s1) * (1.f / D), c2 = wave_sum64(s2) * (1.f / D), r = a.rstd2[(size_t)b * a.rs_ld];
+    float dx[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) dx[u] = s_dx[lane + 64 * u] + r * (v[u] - c1 - h[u] * c2);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int c = lane + 64 * u;
+      const bf16 xb = (bf16)dx[u];
+      s_dx[c] = (float)xb;
+      a.xmid[(size_t)b * a.row_ld192 + c] = xb;
+    }
+  }
+  __syncthreads();
+  // proj dgrad: dO[i] = sum_n xmid[n] Wp[n][i]; thread = (8 consecutive i, one of 32 slices of 6 rows n)
+  if (tid < 768) {
+    const int ic = tid % 24, sl = tid / 24;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 6 * sl; n < 6 * sl + 6; ++n) {
+      const bf16x8 w = *(const bf16x8*)(a.wproj + (size_t)n * D + 8 * ic);
+      const float x = s_dx[n];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(x, (float)w[e], acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_part[sl * D + 8 * ic + e] = acc[e];
+  }
+  __syncthreads();
+  if (tid < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 32; ++sl) t += s_part[sl * D + tid];
+    a.dO[(size_t)b * a.row_ld192 + tid] = (bf16)t;
+  }
+}
+
 }  // namespace
 
 // (internal, common.h) rows: the class-token rows of `rows` images, row b of every dense buffer at b * tokens rows
@@ -138,5 +271,24 @@ int rovit_cls_tail_fwd(const void* o, float* X, const void* wproj, const float* 
   a.feat = feat; a.xhat_cls = xhat_cls; a.rstd_cls = rstd_cls; a.eps = eps;
   hipLaunchKernelGGL(cls_tail_fwd_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, a);
   ROVIT_CHECK_LAUNCH("cls_tail_fwd_kernel");
+  return ROVIT_OK;
+}
+
+// (internal, common.h) the backward chain of the same rows: writes the class-token rows of xin (bf16 gradient entering the block), dpre,
+// xmid (mid-block gradient) and dO
+int rovit_cls_tail_bwd(const float* dfeat, const float* xhat_cls, const float* rstd_cls, const float* gamma, const void* wfc2, const void* wfc1,
+                       const void* wproj, const void* dact, const void* xhat2, const float* rstd2, void* xin, void* dpre, void* xmid, void* dO,
+                       int rows, int tokens, rovit_stream_t stream) {
+  ROVIT_CHECK_ARG(dfeat && xhat_cls && rstd_cls && gamma && wfc2 && wfc1 && wproj && dact && xhat2 && rstd2 && xin && dpre && xmid && dO,
+                  ROVIT_ERR_NULL, "cls_tail_bwd: null pointer");
+  ROVIT_CHECK_ARG(rows > 0 && tokens > 0, ROVIT_ERR_SHAPE, "cls_tail_bwd: bad shape");
+  ROVIT_CHECK_ARG(rovit_aligned16(wproj) && rovit_aligned16(wfc1) && rovit_aligned16(wfc2), ROVIT_ERR_ALIGN, "cls_tail_bwd: weight images must be 16-byte aligned");
+  ClsTailBwdArgs a{};
+  a.dfeat = dfeat; a.xhat_cls = xhat_cls; a.rstd_cls = rstd_cls; a.gamma = gamma;
+  a.wfc2 = (const bf16*)wfc2; a.wfc1 = (const bf16*)wfc1; a.wproj = (const bf16*)wproj;
+  a.dact = (const bf16*)dact; a.act_ld = (long)tokens * MLP; a.xhat2 = (const bf16*)xhat2; a.xh_ld = (long)tokens * D; a.rstd2 = rstd2; a.rs_ld = tokens;
+  a.xin = (bf16*)xin; a.dpre = (bf16*)dpre; a.xmid = (bf16*)xmid; a.dO = (bf16*)dO; a.row_ld192 = (long)tokens * D; a.row_ld768 = (long)tokens * MLP;
+  hipLaunchKernelGGL(cls_tail_bwd_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, a);
+  ROVIT_CHECK_LAUNCH("cls_tail_bwd_kernel");
   return ROVIT_OK;
 }

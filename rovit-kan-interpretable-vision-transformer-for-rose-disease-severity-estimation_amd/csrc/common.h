@@ -212,6 +212,9 @@ int rovit_cls_norm_affine_grad(const float* dfeat, const float* xhat, float* dga
 int rovit_cls_tail_fwd(const void* o, float* X, const void* wproj, const float* bproj, const void* wfc1, const float* bfc1, const void* wfc2,
                        const float* bfc2, const float* gamma, const float* beta, void* xhat2, float* rstd2, void* act, void* dact, float* feat,
                        float* xhat_cls, float* rstd_cls, int rows, int tokens, float eps, rovit_stream_t stream);
+int rovit_cls_tail_bwd(const float* dfeat, const float* xhat_cls, const float* rstd_cls, const float* gamma, const void* wfc2, const void* wfc1,
+                       const void* wproj, const void* dact, const void* xhat2, const float* rstd2, void* xin, void* dpre, void* xmid, void* dO,
+                       int rows, int tokens, rovit_stream_t stream);
 // attention backward whose dout carries gradient on the first `dout_rows` rows of every image only (the last block: the class token's)
 int rovit_attention_bwd_rows(const void* qkv, const void* out, const float* lse2, const void* dout, int dout_rows, void* dqkv, int batch,
                              int tokens, int heads, int head_dim, float scale, rovit_stream_t stream);

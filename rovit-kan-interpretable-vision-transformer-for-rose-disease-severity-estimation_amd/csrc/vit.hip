@@ -462,7 +462,7 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
   char* ws = (char*)workspace;
   const int M = (int)L.M;
   const bool one_launch = mlp_one_launch(mlp_path, M);       // the SAME decision the forward took (same argument, same row count)
-  float* dX = (float*)(ws + L.dX);        // fp32, used on the CLS rows of the last block only (round 4)
+  // (L.dX: the fp32 gradient rows of rounds 1-3; the last block's class-token chain keeps its fp32 sums on chip since cls_tail.hip)
   // Round 4: the residual-stream gradient travels between the kernels in BF16 -- every LayerNorm-backward epilogue reads the incoming
   // gradient's bf16 rows, adds its term in fp32 and writes bf16 rows; rounds 1-3 also read and wrote an fp32 dX per kernel (116 MB per
   // block at batch 256 = 11 % of the backward's bytes; bound measured first, developer knob 15: 4.465 -> 4.33 ms with the fp32 stores
@@ -472,10 +472,7 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
   auto x0v = [&](int i) { return ws + L.x0[(i + 3) % 3]; };
   if (first_block == depth - 1) {
     ROVIT_CHECK_ARG(d_features, ROVIT_ERR_NULL, "vit_backward: null d_features");
-    // (the final norm's dgamma / dbeta -- sample sums off the dgrad chain -- go to the weight-gradient stream below when there is one)
-    const bool affine_on_b = two_streams_enabled() && side_stream() != nullptr;
-    RUN(rovit_cls_norm_bwd(d_features, (const float*)(ws + L.xhat_cls), (const float*)(ws + L.rstd_cls), params[P_NORM_W], dX,
-                           x0v(depth - 1), affine_on_b ? nullptr : grads[P_NORM_W], affine_on_b ? nullptr : grads[P_NORM_B], batch, T, 0, stream));
+    // (the final norm's backward opens the last block's fused class-token chain below: cls_tail.hip)
   }
   // Two-stream schedule (see SideStream above).  Per block i (p = i & 1), stream A runs the dgrad chain
   //   A1 + A2 MLP half (fc2 dgrad * gelu' -> dpre[p]; fc1 dgrad + norm2 bwd -> dX, x1[p]): one launch from batch 173, else two
@@ -561,17 +558,14 @@ int vit_backward_impl(const float* images, const float* d_features, const float*
       char* dp = ws + L.dpre[i & 1];
       char* dq = ws + L.dqkv[i & 1];
       char* xmc = ws + L.x1[i & 1];
-      RUN(rovit_gemm_nt(xin, D * rs, q + P.wfc2T, D, Mr, MLP, D, nullptr, EPI_MUL, dp, MLP * rs, nullptr, nullptr, 0, s + L.dact,
-                        MLP * rs, nullptr, 0, stream));
-      RUN(rovit_gemm_nt(dp, MLP * rs, q + P.wfc1T, MLP, Mr, D, MLP, nullptr, EPI_BF16, ws + L.dxhat, D * rs, nullptr, nullptr, 0, nullptr, 0,
-                        nullptr, 0, stream));
-      RUN(rovit_layernorm_bwd_rows(ws + L.dxhat, s + L.xhat2, (const float*)(s + L.rstd2), dX, xmc, batch, T, stream));
+      // final-norm backward -> fc2 dgrad x gelu' -> fc1 dgrad -> norm2 backward -> proj dgrad on the class-token rows: ONE launch (five before)
+      RUN(rovit_cls_tail_bwd(d_features, (const float*)(ws + L.xhat_cls), (const float*)(ws + L.rstd_cls), params[P_NORM_W], q + P.wfc2, q + P.wfc1,
+                             q + P.wproj, s + L.dact, s + L.xhat2, (const float*)(s + L.rstd2), xin, dp, xmc, ws + L.dO, batch, T, stream));
       // (no zero fills, round 4: only the CLS rows of dO and of the mid-block gradient carry gradient; the attention backward and the
       // qkv dgrad below are told so and treat the other rows as zeros without reading them)
-      RUN(rovit_gemm_nt(xmc, D * rs, q + P.wprojT, D, Mr, D, D, nullptr, EPI_BF16, ws + L.dO, D * rs, nullptr, nullptr, 0, nullptr, 0, nullptr,
-                        0, stream));
       if (ss && !hand_over(ss, sA, sB)) EVFAIL("event hand-over");
-      if (ss) RUN(rovit_cls_norm_affine_grad(d_features, (const float*)(ws + L.xhat_cls), grads[P_NORM_W], grads[P_NORM_B], batch, sB));
+      // the final norm's dgamma / dbeta: sample sums off the dgrad chain -> the weight-gradient stream
+      RUN(rovit_cls_norm_affine_grad(d_features, (const float*)(ws + L.xhat_cls), grads[P_NORM_W], grads[P_NORM_B], batch, sB));
       {
         const float* const* bpp = params + P_BLOCK0 + B_COUNT * i;
         float* const* bg = grads + P_BLOCK0 + B_COUNT * i;

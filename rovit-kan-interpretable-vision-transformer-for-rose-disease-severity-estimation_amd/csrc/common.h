@@ -201,12 +201,9 @@ struct RovitPrepDesc {
 constexpr int ROVIT_PREP_BATCH = 52;     // 1 + 4*12 descriptors of a depth-12 backbone in ONE launch (3.5 KB of kernel arguments)
 int rovit_prep_weight_batch(const RovitPrepDesc* descs, int n, rovit_stream_t stream);
 
-// LayerNorm forward / backward on every row_step-th row of the dense (rows*row_step, 192) buffers, in place
+// LayerNorm forward on every row_step-th row of the dense (rows*row_step, 192) buffers, in place (the taps path of the last block)
 void rovit_set_cu_budget(int cus);   // gemm.hip: CUs the weight-stationary GEMM launches size their grids for
 int rovit_layernorm_fwd_rows(const float* x, void* xhat, float* rstd, int rows, int row_step, float eps, rovit_stream_t stream);
-int rovit_layernorm_bwd_rows(const void* dxhat, const void* xhat, const float* rstd, float* dX, void* dXb, int rows, int row_step,
-                             rovit_stream_t stream);
-
 int rovit_cls_norm_affine_grad(const float* dfeat, const float* xhat, float* dgamma, float* dbeta, int batch, rovit_stream_t stream);
 // cls_tail.hip: the last block's post-attention half + the final norm on the class-token rows in one launch
 int rovit_cls_tail_fwd(const void* o, float* X, const void* wproj, const float* bproj, const void* wfc1, const float* bfc1, const void* wfc2,

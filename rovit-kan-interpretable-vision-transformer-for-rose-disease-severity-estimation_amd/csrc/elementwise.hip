@@ -348,14 +348,6 @@ int rovit_layernorm_fwd_rows(const float* x, void* xhat, float* rstd, int rows, 
   return ROVIT_OK;
 }
 
-int rovit_layernorm_bwd_rows(const void* dxhat, const void* xhat, const float* rstd, float* dX, void* dXb, int rows, int row_step,
-                             rovit_stream_t stream) {
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const bf16*)dxhat,
-                     (const bf16*)xhat, rstd, dX, (bf16*)dXb, rows, (size_t)D * row_step, (size_t)row_step);
-  ROVIT_CHECK_LAUNCH("ln_bwd_kernel");
-  return ROVIT_OK;
-}
-
 extern "C" int rovit_layernorm_bwd(const void* dxhat, const void* xhat, const float* rstd, float* dX, void* dXb, int rows,
                                    int dim, rovit_stream_t stream) {
   ROVIT_CHECK_ARG(dxhat && xhat && rstd && dX && dXb, ROVIT_ERR_NULL, "layernorm_bwd: null pointer");

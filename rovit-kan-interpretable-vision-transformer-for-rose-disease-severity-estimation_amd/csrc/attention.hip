@@ -160,6 +160,134 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(const AttnArgs a) 
   }
 }
 
+#ifdef ROVIT_DEV   // measured no faster (below): developer library only, knob 20
+// Forward, round 4 (late): THREE workgroups per CU = all 768 (image, head) items of a batch-256 launch resident at once (two per CU are 1.5
+// rounds: a third of the launch runs with half the chip's slots empty).  What it takes:
+//   * LDS: K and V as UNPADDED 208-row tiles (13 key tiles; 128-byte rows: 53 248 bytes per workgroup, 3 x = 159 744 of the CU's 163 840).
+//     Unpadded rows alone put every second row on the same banks; the 16-byte chunk index is XOR-swizzled with f(row) = (bit 2 of the row) << 1
+//     | (bit 1) << 2, found by brute force over the linear swizzles against the bank model of MI355X_MICROARCH.md (ds_read_b128: four groups of 16
+//     lanes; ds_read_b64_tr_b16: two groups of 32): conflict-free for the row-fragment reads AND the transposed column-fragment reads -- the
+//     same model calls the 160-byte padded rows conflict-free and unpadded unswizzled rows conflicted (tools/lds_swizzle_search.py);
+//   * registers: <= 80 for six waves per SIMD.  The 52 score registers of a query tile go: the scores are computed TWICE -- a first sweep over
+//     the 13 key tiles keeps only the running maximum, a second one recomputes each 32-key block's scores, exponentiates them against that
+//     maximum and feeds the P V product at once.  +26 MFMAs and +26 fragment reads per query tile in a kernel whose matrix pipe is 14 % busy.
+// Same products and maximum as attn_fwd_kernel; outputs within one bf16 ulp of it (tools/_f3chk.py).  MEASURED (tools/ab_attn_fwd3.sh, one box,
+// batch 256): 27.6 / 26.8 us per launch against 27.3 / 26.2 for the two-workgroup kernel, whole steps 4.10 / 4.07 against 4.05 / 4.04 ms: NO
+// gain -- the third workgroup's residency buys what the second score sweep costs.  (A first version that spilled 14-24 registers at the
+// 80-register cap also produced wrong results; this one, 68 registers, does not spill.)
+constexpr int TK3 = 208;                 // key rows in LDS (13 tiles of 16); T <= 208
+#ifdef ATTN3_NOSWZ
+__device__ __forceinline__ int swz3(int row) { return 0; }
+#else
+__device__ __forceinline__ int swz3(int row) { return (((row >> 2) & 1) << 1) | (((row >> 1) & 1) << 2); }
+#endif
+#ifndef ATTN3_LB
+#define ATTN3_LB 6
+#endif
+__global__ __launch_bounds__(NW * 64, ATTN3_LB) void attn_fwd3_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) bf16 lds[];
+  bf16* Ks = lds;
+  bf16* Vs = lds + TK3 * HD;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int ld = 3 * a.H * HD;
+  const bf16* base = a.qkv + (size_t)b * a.T * ld + h * HD;
+  // stage K and V: 208 rows x 8 chunks of 16 bytes each, rows beyond T zero
+  for (int c = tid; c < TK3 * 8; c += NW * 64) {
+    const int row = c >> 3, kc = c & 7;
+    const int rc = row < a.T ? row : a.T - 1;
+    const int dst = row * HD + ((kc ^ swz3(row)) << 3);
+    *(bf16x8*)(Ks + dst) = keep_if(*(const bf16x8*)(base + a.H * HD + (size_t)rc * ld + kc * 8), row < a.T);
+    *(bf16x8*)(Vs + dst) = keep_if(*(const bf16x8*)(base + 2 * a.H * HD + (size_t)rc * ld + kc * 8), row < a.T);
+  }
+  // Per-lane fragment offsets, computed once: the swizzle reads bits 1-2 of the row only, and neither 16 kt (row fragments) nor 32 kb
+  // (column fragments) touches them.  Row fragment (key tile kt, k-step ks): Ks + 16 kt HD + koff[ks]; column fragment (key block kb, d-tile dt):
+  // Vs + 32 kb HD + voff[dt] and the same + 16 HD.
+  int koff[2], voff[4];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) koff[ks] = l15 * HD + (((4 * ks + lg) ^ swz3(l15)) << 3);
+  {
+    const int rl = 4 * lg + (l15 >> 2);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) voff[dt] = rl * HD + (((2 * dt + ((l15 >> 1) & 1)) ^ swz3(rl)) << 3) + 4 * (l15 & 1);
+  }
+  __syncthreads();
+  const float c2 = a.scale * LOG2E;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q0 = 32 * w + 16 * qt;
+    if (q0 >= a.T) break;                             // wave-uniform: nothing of this tile is stored
+    const int qrow = q0 + l15;
+    bf16x8 qf[2];
+    {
+      const int qc = qrow < a.T ? qrow : a.T - 1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(base + (size_t)qc * ld + ks * 32 + lg * 8);
+    }
+    auto scores = [&](int kt) -> f32x4 {
+      const bf16* kp = Ks + 16 * kt * HD;
+      f32x4 s = mfma16(*(const bf16x8*)(kp + koff[1]), qf[1], mfma16(*(const bf16x8*)(kp + koff[0]), qf[0], zero4));
+      if (16 * kt + 16 > a.T) {                       // wave-uniform: the tile straddles T
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * kt + 4 * lg + r >= a.T) s[r] = -INFINITY;
+      }
+      return s;
+    };
+    // sweep 1: the row maximum
+    float m = -INFINITY;
+#pragma unroll 1
+    for (int kt = 0; kt < 13; ++kt) {
+      const f32x4 s = scores(kt);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, s[r]);
+    }
+    m = group4_max(m);
+    const float mc = m * c2;
+    // sweep 2: scores again, block by block; exponentials; P V
+    float l = 0.f;
+    f32x4 o[4] = {zero4, zero4, zero4, zero4};
+    auto block = [&](int kb, auto last) {
+      constexpr bool LAST = decltype(last)::value;       // key block 6: keys 192 .. 207 only (no tile 13, and no V rows beyond 207)
+      f32x4 p0 = scores(2 * kb), p1 = zero4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { p0[r] = __builtin_amdgcn_exp2f(fmaf(p0[r], c2, -mc)); l += p0[r]; }
+      if (!LAST) {
+        p1 = scores(2 * kb + 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p1[r] = __builtin_amdgcn_exp2f(fmaf(p1[r], c2, -mc)); l += p1[r]; }
+      }
+      const bf16x8 pf = pack8(p0, p1);
+      const bf16* vp = Vs + 32 * kb * HD;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x4 lo = lds_read_tr(vp + voff[dt]);
+        const bf16x4 hi = lds_read_tr(LAST ? vp + voff[dt] : vp + voff[dt] + 16 * HD);      // LAST: those keys carry p = 0; read rows that exist
+        o[dt] = mfma16(cat4(lo, hi), pf, o[dt]);
+      }
+    };
+#pragma unroll 1
+    for (int kb = 0; kb < 6; ++kb) block(kb, std::false_type());
+    block(6, std::true_type());
+    l = group4_sum(l);
+    const float inv_l = 1.f / l;
+    if (lg == 0 && qrow < a.T && a.lse2) a.lse2[((size_t)b * a.H + h) * a.T + qrow] = mc + log2f(l);
+    if (qrow < a.T) {
+      bf16* dst = a.out + ((size_t)b * a.T + qrow) * (a.H * HD) + h * HD + 4 * lg;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        f32x4 v = o[dt];
+        v[0] *= inv_l; v[1] *= inv_l; v[2] *= inv_l; v[3] *= inv_l;
+        *(bf16x4*)(dst + 16 * dt) = pack4(v);
+      }
+    }
+  }
+}
+
+#endif  // ROVIT_DEV (attn_fwd3_kernel)
+
 #ifdef ROVIT_DEV   // round 3's forward (both query tiles of a wave in registers, one workgroup per CU): A/B in the developer build only
 // launch bound: 4 waves/SIMD (<= 128 VGPRs) so that TWO 7-wave workgroups share a CU (70 KB of LDS each) and one
 // stages its K/V tiles while the other computes.
@@ -1014,6 +1142,15 @@ extern "C" int rovit_attention_fwd(const void* qkv, void* out, float* lse2, int 
     ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)attn_fwd_kernel_r3, lds), ROVIT_ERR_LAUNCH, "attention_fwd: cannot raise the LDS limit");
     hipLaunchKernelGGL(attn_fwd_kernel_r3, dim3(batch * heads), dim3(NW * 64), lds, (hipStream_t)stream, a);
     ROVIT_CHECK_LAUNCH("attn_fwd_kernel_r3");
+    return ROVIT_OK;
+  }
+#endif
+#ifdef ROVIT_DEV
+  if (ROVIT_KNOB(ROVIT_KNOB_ATTN_FWD3, 0)) {       // three workgroups per CU (unpadded swizzled tiles, scores computed twice)
+    const size_t lds3 = (size_t)2 * TK3 * HD * sizeof(bf16);
+    ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)attn_fwd3_kernel, lds3), ROVIT_ERR_LAUNCH, "attention_fwd: cannot raise the LDS limit");
+    hipLaunchKernelGGL(attn_fwd3_kernel, dim3(batch * heads), dim3(NW * 64), lds3, (hipStream_t)stream, a);
+    ROVIT_CHECK_LAUNCH("attn_fwd3_kernel");
     return ROVIT_OK;
   }
 #endif

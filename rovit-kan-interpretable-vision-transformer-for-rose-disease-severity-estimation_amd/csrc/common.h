@@ -66,6 +66,7 @@ enum RovitKnob {
   ROVIT_KNOB_PROJ_DGRAD_CUS = 17, // CUs the proj dgrad launch of the backward sizes its grid for (default 256)
   ROVIT_KNOB_TAIL_WAVES = 18,    // waves per workgroup of the forward block tail: 8 (two row tiles per wave) or 16 (one; four waves per SIMD)
   ROVIT_KNOB_FWD_STAGGER = 19,   // 1: the forward's second half-batch starts one attention launch behind the first
+  ROVIT_KNOB_ATTN_FWD3 = 20,     // 1: attention forward with three workgroups per CU (attn_fwd3_kernel)
   ROVIT_KNOB_SKIP_WGRAD_REDUCE = 14,  // 1: the slab-reduce / affine-finalize launches are not issued (gradients WRONG): upper bound of what folding them away could gain
   ROVIT_KNOB_COUNT = 32
 };

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_kernel(const AttnArgs a) 
 //   * registers: <= 80 for six waves per SIMD.  The 52 score registers of a query tile go: the scores are computed TWICE -- a first sweep over
 //     the 13 key tiles keeps only the running maximum, a second one recomputes each 32-key block's scores, exponentiates them against that
 //     maximum and feeds the P V product at once.  +26 MFMAs and +26 fragment reads per query tile in a kernel whose matrix pipe is 14 % busy.
-// Same products and maximum as attn_fwd_kernel; outputs within one bf16 ulp of it (tools/_f3chk.py).  MEASURED (tools/ab_attn_fwd3.sh, one box,
+// Same products and maximum as attn_fwd_kernel; outputs within one bf16 ulp of it (tools/attn_fwd3_check.py).  MEASURED (tools/ab_attn_fwd3.sh, one box,
 // batch 256): 27.6 / 26.8 us per launch against 27.3 / 26.2 for the two-workgroup kernel, whole steps 4.10 / 4.07 against 4.05 / 4.04 ms: NO
 // gain -- the third workgroup's residency buys what the second score sweep costs.  (A first version that spilled 14-24 registers at the
 // 80-register cap also produced wrong results; this one, 68 registers, does not spill.)

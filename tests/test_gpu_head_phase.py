@@ -187,25 +187,10 @@ def test_dropout_drawn_in_the_kernel_statistics_determinism_and_backward():
 
 
 def _philox_masks(B, hid, p, seed, offset):
-    """Host restatement of the kernel's draw (csrc/head_phase.hip: Philox4x32-10, key = seed, counter = (sample * hid + unit, 0,
-    offset lo, offset hi); words x / y / z of the output serve the three heads; kept iff (word >> 8) * 2^-24 < 1 - p)."""
-    import numpy as np
-    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
-    n = B * hid
-    c = [np.arange(n, dtype=np.uint64), np.zeros(n, np.uint64), np.full(n, offset & 0xFFFFFFFF, np.uint64), np.full(n, offset >> 32, np.uint64)]
-    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32)
-    mask32 = np.uint64(0xFFFFFFFF)
-    for _ in range(10):
-        p0, p1 = M0 * c[0], M1 * c[2]
-        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask32, p1 >> np.uint64(32), p1 & mask32
-        c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
-        k0 = (k0 + np.uint64(0x9E3779B9)) & mask32
-        k1 = (k1 + np.uint64(0xBB67AE85)) & mask32
-    out = []
-    for w in c[:3]:
-        u = (w >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
-        out.append(torch.from_numpy(np.where(u < np.float32(1.0 - p), np.float32(1.0 / (1.0 - p)), np.float32(0.0)).reshape(B, hid)))
-    return out
+    """The kernel's draw restated on the host (oracle/philox.py, itself pinned to the published Philox4x32-10 known-answer vectors by
+    tests/test_oracle.py)."""
+    from oracle.philox import head_phase_masks
+    return [torch.from_numpy(m) for m in head_phase_masks(B, hid, p, seed, offset)]
 
 
 def test_training_step_uses_the_fused_phase_and_writes_gradients_into_the_optimizers_flat_buffer():

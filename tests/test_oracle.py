@@ -181,3 +181,23 @@ def test_config1_plumbing_cpu():
     assert out['ordinal_logits'].shape == (8, 3) and out['mu'].shape == (8, 1) and out['log_var'].shape == (8, 1)
     assert out['kan_severity'].shape == (8, 1)
     assert float(out['kan_severity'].min()) >= 0 and float(out['kan_severity'].max()) <= 3
+
+
+def test_philox_restatement_against_the_published_known_answer_vectors():
+    """oracle/philox.py (the checker of the dropout masks the fused head-phase kernel draws) against the known-answer vectors of the
+    Random123 distribution for philox4x32 with 10 rounds (Salmon et al., SC'11: kat_vectors), and the mask helper's shape / scaling."""
+    import numpy as np
+    from oracle.philox import head_phase_masks, philox4x32_10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert tuple(int(x) for x in philox4x32_10(ctr, key)) == want
+    masks = head_phase_masks(64, 128, 0.3, 1234, 40)
+    assert len(masks) == 3 and all(m.shape == (64, 128) and m.dtype == np.float32 for m in masks)
+    for m in masks:
+        vals = np.unique(m)
+        assert set(vals.tolist()) <= {0.0, float(np.float32(1.0) / (np.float32(1.0) - np.float32(0.3)))}
+        assert abs(float((m > 0).mean()) - 0.7) < 0.03
+    assert not np.array_equal(masks[0], masks[1])
+    assert not np.array_equal(masks[0], head_phase_masks(64, 128, 0.3, 1234, 44)[0])          # another offset, another draw

@@ -204,6 +204,8 @@ int rovit_prep_weight_batch(const RovitPrepDesc* descs, int n, rovit_stream_t st
 
 // LayerNorm forward on every row_step-th row of the dense (rows*row_step, 192) buffers, in place (the taps path of the last block)
 void rovit_set_cu_budget(int cus);   // gemm.hip: CUs the weight-stationary GEMM launches size their grids for
+// vit.hip: the device's second stream (created on first use; nullptr on failure or when the developer library asks for a single stream)
+hipStream_t rovit_side_stream_handle();
 int rovit_layernorm_fwd_rows(const float* x, void* xhat, float* rstd, int rows, int row_step, float eps, rovit_stream_t stream);
 int rovit_cls_norm_affine_grad(const float* dfeat, const float* xhat, float* dgamma, float* dbeta, int batch, rovit_stream_t stream);
 // cls_tail.hip: the last block's post-attention half + the final norm on the class-token rows in one launch

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NW * 64, TPW == 1 ? 4 : 2) void mlp_fused_kernel(co
   static_assert(!STAG || (KIND == 0 && NW == 8), "the staggered schedule is the 8-wave forward's");
   static_assert(!PIPE || (KIND == 0 && (NW == 8 || NW == 16) && !STAG), "the pipelined schedule is the 8- / 16-wave forward's");
   constexpr int S = TPW * MODE;               // stores one wave issues per chunk
-  constexpr int ROWS = 16 * TPW * NW;         // rows per workgroup: wave w owns the 16-row tiles w and w + NW
+  // (rows per workgroup = 16 * TPW * NW: wave w owns the 16-row tiles w and w + NW)
   // DMA pieces one wave issues per chunk: 24 / NW, or (NW = 16) two for waves 0-7 and one for waves 8-15 -- the counted waits differ by wave
   constexpr int PWHI = (CH_PIECES + NW - 1) / NW, PWLO = CH_PIECES / NW, PWREM = CH_PIECES % NW;
   constexpr int PW = PWLO + (KIND ? 2 : 0);

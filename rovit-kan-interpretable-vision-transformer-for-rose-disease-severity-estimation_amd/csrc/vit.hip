@@ -190,6 +190,12 @@ int check_common(const void* params, const void* prep, const void* ws, int batch
 
 }  // namespace
 
+hipStream_t rovit_side_stream_handle() {
+  if (!two_streams_enabled()) return nullptr;
+  SideStream* s = side_stream();
+  return s ? s->stream : nullptr;
+}
+
 extern "C" size_t rovit_vit_prep_bytes(int depth) { return Prep(depth).total; }
 extern "C" size_t rovit_vit_workspace_bytes(int batch, int depth, int training) { return Plan(batch, depth, training).total; }
 extern "C" int rovit_vit_num_params(int depth) { return P_BLOCK0 + B_COUNT * depth; }

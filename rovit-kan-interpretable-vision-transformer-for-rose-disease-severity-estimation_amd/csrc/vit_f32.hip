@@ -34,7 +34,9 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 //   F_PATCH: A is gathered from the NCHW image (row m = image b, patch p; k = c*256 + py*16 + px), the result goes to token
 //            row b*T + 1 + p with the position embedding added (timm PatchEmbed + pos_embed)
 constexpr int GBM = 128, GBN = 192, GBK = 32, GST = GBK + 4;     // GST: LDS row stride in floats
-template <int EPI>
+// (LAB: ablation bits of tools/f32_gemm_lab.hip -- 1 no global loads inside the loop, 2 no restaging at all, 4 no epilogue; the library
+// instantiates LAB = 0 only)
+template <int EPI, int LAB = 0>
 __global__ __launch_bounds__(512, 2) void gemm_f32_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W,
                                                               const float* __restrict__ bias, float* __restrict__ C, int ldc, int M, int N,
                                                               int K, const float* __restrict__ pos) {
@@ -75,13 +77,15 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_mfma_kernel(const float* __re
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   for (int k0 = 0; k0 < K; k0 += GBK) {
+    if (!(LAB & 2) || k0 == 0) {
     __syncthreads();                                               // every wave is done reading the previous stage
 #pragma unroll
     for (int q = 0; q < 2; ++q) *(float4*)&As[(srow + 64 * q) * GST + 4 * sch] = pa[q];
 #pragma unroll
     for (int q = 0; q < 3; ++q) *(float4*)&Ws[(srow + 64 * q) * GST + 4 * sch] = pw[q];
     __syncthreads();
-    if (k0 + GBK < K) {                                            // next stage: in flight while this one is computed
+    }
+    if (!(LAB & 3) && k0 + GBK < K) {                              // next stage: in flight while this one is computed
 #pragma unroll
       for (int q = 0; q < 2; ++q) pa[q] = load_a(q, k0 + GBK);
 #pragma unroll
@@ -89,10 +93,16 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_mfma_kernel(const float* __re
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const float4 a4 = *(const float4*)&As[(32 * wm + l31) * GST + 8 * c + 4 * lh];
-      float4 b4[3];
+      float4 a4, b4[3];
+      if ((LAB & 8) && k0 > 0) {                                   // (lab: the matrix instructions alone, on whatever the registers hold)
+        a4 = pa[0];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) b4[t] = *(const float4*)&Ws[(96 * wn + 32 * t + l31) * GST + 8 * c + 4 * lh];
+        for (int t = 0; t < 3; ++t) b4[t] = pw[t];
+      } else {
+        a4 = *(const float4*)&As[(32 * wm + l31) * GST + 8 * c + 4 * lh];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) b4[t] = *(const float4*)&Ws[(96 * wn + 32 * t + l31) * GST + 8 * c + 4 * lh];
+      }
       const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
       for (int sidx = 0; sidx < 4; ++sidx)
@@ -112,6 +122,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_mfma_kernel(const float* __re
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (m >= M) continue;
+      if ((LAB & 4) && acc[t][r] != 12345.678f) continue;
       float v = acc[t][r] + bn;
       if (EPI == F_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));      // exact-erf GELU (timm default)
       if (EPI == F_PATCH) {
@@ -144,19 +155,22 @@ __global__ __launch_bounds__(256) void ln_f32_kernel(const float* __restrict__ x
   for (int i = 0; i < 3; ++i) y[(size_t)row * D + lane + 64 * i] = v[i] * rstd * gamma[lane + 64 * i] + beta[lane + 64 * i];
 }
 
-// softmax(q k^T * scale) v for one (image, head) on the fp32 matrix cores: K and V (224 zero-padded rows x 64 fp32, rows padded to
-// 68 floats) in LDS, wave w owns queries 32w .. 32w + 31.
+// softmax(q k^T * scale) v for one (image, head) on the fp32 matrix cores: K and V (200 rows x 64 fp32, zero beyond T, rows padded to
+// 68 floats) in LDS, wave w owns queries 32w .. 32w + 31.  (The seventh key tile reads K rows 200 .. 223 out of the V area: whatever lies
+// there, those scores are REPLACED by -inf before the softmax, and a row of S^T depends on its own K row only.  V needs rows up to 199:
+// the last contraction steps pair key 192 + j with 196 + j.  200 rows keep the tile pair at 106 KB so that a GEMM workgroup of the other
+// half-batch (45 KB) fits on the same CU.)
 //   S^T[key][q] = K Q^T: A = K rows from LDS (one 16-byte read feeds 4 MFMAs), B = the wave's scaled Q rows in 32 registers (lane half h
 //   holds d = 32h + s for step s -- the same map on the K side); seven 32 x 32 accumulator tiles = the whole 224-key column block.
 //   softmax down the accumulator registers of a lane (+ one exchange with lane ^ 32), exact expf, masked beyond T.
 //   O^T[d][q] = V^T P^T: the probabilities ARE the B operand as they stand -- register r of tile kt holds key 32kt + (r&3) + 8(r>>2) + 4h,
 //   so step r contracts over exactly those two keys and the A operand is V[that key][32 dt + lane & 31] (a 128-byte row read per half).
 // Output through a wave-private LDS patch (in the K tile, free behind a barrier) so that rows leave as 256-byte runs.
-constexpr int AKS = HD + 4, ATP = 224, ANW = 7;
-__global__ __launch_bounds__(ANW * 64) void attn_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, float scale) {
+constexpr int AKS = HD + 4, ATP = 224, ATR = 200, ANW = 7;
+__global__ __launch_bounds__(ANW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void attn_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, float scale) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Ks = sm;
-  float* Vs = sm + ATP * AKS;
+  float* Vs = sm + ATR * AKS;
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
   const int ld = 3 * D;
   const float* base = qkv + (size_t)b * T * ld + h * HD;
@@ -165,41 +179,58 @@ __global__ __launch_bounds__(ANW * 64) void attn_f32_mfma_kernel(const float* __
   // K goes to LDS now; V is only REQUESTED here (8 x 16 bytes per thread in registers) and written behind the S products, so its
   // latency hides under the first matrix phase (one workgroup per CU: nothing else would cover it)
   static_assert(ATP * 16 == 8 * ANW * 64, "8 chunks of a tile per thread");
-  float4 vreg[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int e = tid + i * ANW * 64, r = e >> 4, c = e & 15, rc = r < T ? r : T - 1;
-    float4 kv = *(const float4*)(base + (size_t)rc * ld + D + 4 * c);
-    vreg[i] = *(const float4*)(base + (size_t)rc * ld + 2 * D + 4 * c);
-    if (r >= T) { kv = make_float4(0.f, 0.f, 0.f, 0.f); vreg[i] = kv; }
-    *(float4*)&Ks[r * AKS + 4 * c] = kv;
-  }
   const int q0 = 32 * w;
   const bool active = q0 < T;                           // wave-uniform; inactive waves only keep the barriers company
-  float qv[32];
+  float4 qraw[8];                                       // the wave's 32 query rows: lane half h holds d = 32h .. 32h + 31 of row q0 + lane & 31
   {
     const int qr = q0 + l31, qc = qr < T ? qr : T - 1;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float4 t = *(const float4*)(base + (size_t)qc * ld + 32 * lh + 4 * i);
-      qv[4 * i] = t.x * scale; qv[4 * i + 1] = t.y * scale; qv[4 * i + 2] = t.z * scale; qv[4 * i + 3] = t.w * scale;   // timm scales q first
-    }
+    for (int i = 0; i < 8; ++i) qraw[i] = *(const float4*)(base + (size_t)qc * ld + 32 * lh + 4 * i);
+  }
+  float4 vreg[8], kreg[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {                         // all 24 requests of the thread are in flight before the first one is waited for
+    const int e = tid + i * ANW * 64, r = e >> 4, c = e & 15, rc = r < T ? r : T - 1;
+    kreg[i] = *(const float4*)(base + (size_t)rc * ld + D + 4 * c);
+    vreg[i] = *(const float4*)(base + (size_t)rc * ld + 2 * D + 4 * c);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = tid + i * ANW * 64, r = e >> 4, c = e & 15;
+    if (r >= T) { kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f); vreg[i] = kreg[i]; }
+    if (r < ATR) *(float4*)&Ks[r * AKS + 4 * c] = kreg[i];
+  }
+  float qv[32];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float4 t = qraw[i];
+    qv[4 * i] = t.x * scale; qv[4 * i + 1] = t.y * scale; qv[4 * i + 2] = t.z * scale; qv[4 * i + 3] = t.w * scale;     // timm scales q first
   }
   __syncthreads();
   f32x16 st[7];
   float inv_l = 0.f;
   if (active) {
+    // the K fragments of step (kt, c) + 2 are requested before the four MFMAs of step (kt, c) are issued (three register sets)
+    const float* krow = &Ks[l31 * AKS + 32 * lh];
+    float4 kf[3];
+    kf[0] = *(const float4*)krow;
+    kf[1] = *(const float4*)(krow + 4);
 #pragma unroll
     for (int kt = 0; kt < 7; ++kt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const float4 k4 = *(const float4*)&Ks[(32 * kt + l31) * AKS + 32 * lh + 4 * c];
+        const int step = 8 * kt + c, nx = step + 2;
+        if (nx < 56) kf[nx % 3] = *(const float4*)(krow + 32 * (nx >> 3) * AKS + 4 * (nx & 7));
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 k4 = kf[step % 3];
         st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, qv[4 * c], st[kt], 0, 0, 0);
         st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, qv[4 * c + 1], st[kt], 0, 0, 0);
         st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, qv[4 * c + 2], st[kt], 0, 0, 0);
         st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, qv[4 * c + 3], st[kt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     float m = -INFINITY;
@@ -227,7 +258,7 @@ __global__ __launch_bounds__(ANW * 64) void attn_f32_mfma_kernel(const float* __
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int e = tid + i * ANW * 64;
-    *(float4*)&Vs[(e >> 4) * AKS + 4 * (e & 15)] = vreg[i];
+    if ((e >> 4) < ATR) *(float4*)&Vs[(e >> 4) * AKS + 4 * (e & 15)] = vreg[i];
   }
   __syncthreads();
   f32x16 o[2];
@@ -236,17 +267,31 @@ __global__ __launch_bounds__(ANW * 64) void attn_f32_mfma_kernel(const float* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   if (active) {
+    // contraction steps in key order: step s = 16 kt + r pairs keys 32 kt + (r & 3) + 8 (r >> 2) (+ 4 in the upper lane half); both keys of
+    // steps 100 .. 111 are padding (T = 197).  The V operands of step s + 3 are requested before the two MFMAs of step s are issued.
+    constexpr int NSTEP = 100;
+    static_assert(T == 197, "step count of the P V product");
+    const float* vbase = &Vs[4 * lh * AKS + l31];
+    float va[4], vb[4];
 #pragma unroll
-    for (int kt = 0; kt < 7; ++kt)
+    for (int s = 0; s < 3; ++s) {
+      const float* vrow = vbase + (32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2)) * AKS;
+      va[s] = vrow[0]; vb[s] = vrow[32];
+    }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (kt == 6 && 192 + (r & 3) + 8 * (r >> 2) >= T) continue;      // compile-time: both keys of the step are padding (T = 197)
-        const float* vrow = &Vs[(32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh) * AKS + l31];
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], st[kt][r], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], st[kt][r], o[1], 0, 0, 0);
+    for (int s = 0; s < NSTEP; ++s) {
+      const int n = s + 3;
+      if (n < NSTEP) {
+        const float* vrow = vbase + (32 * (n >> 4) + (n & 3) + 8 * ((n & 15) >> 2)) * AKS;
+        va[n & 3] = vrow[0]; vb[n & 3] = vrow[32];
       }
+      __builtin_amdgcn_sched_barrier(0);
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s & 3], st[s >> 4][s & 15], o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[s & 3], st[s >> 4][s & 15], o[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
-  __syncthreads();                                      // nobody reads the K tile any more: it becomes seven 32 x 68 output patches
+  __syncthreads();                                      // nobody reads K or V any more: the area becomes seven 32 x 68 output patches
   float* patch = Ks + w * 32 * AKS;
   if (active) {
 #pragma unroll
@@ -279,6 +324,19 @@ int gemm_f32(const float* A, int lda, const float* W, const float* bias, float* 
 }
 
 #define RUN(call) do { int rc__ = (call); if (rc__ != ROVIT_OK) return rc__; } while (0)
+constexpr int F32_TWO_CHAINS_FROM = 192;           // batch from which the forward runs as two half-batch chains (see rovit_vit_forward_f32)
+
+// the two events of the half-batch fork / join, one pair per device
+struct ForkJoin { hipEvent_t fork = nullptr, join = nullptr; };
+ForkJoin* fork_join() {
+  static ForkJoin per_dev[64];
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
+  ForkJoin& f = per_dev[d];
+  if (!f.fork && hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (!f.join && hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  return &f;
+}
 
 }  // namespace
 
@@ -290,11 +348,16 @@ extern "C" size_t rovit_vit_f32_workspace_bytes(int batch) {
 
 // images fp32 NCHW (B,3,224,224) -> features fp32 (B,192), every operation in fp32 (see the file header).  params as for
 // rovit_vit_forward (the ORIGINAL fp32 parameters; no prepared weights).
+// The images are independent, so the batch is cut into two halves that run the same launches on two HIP streams (the caller's and the
+// device's side stream): the tile counts of one half's GEMM never fill the 512 workgroup slots evenly (fc2 of 256 images is 394 tiles:
+// 138 CUs carry two and 118 one), and the other half's launches take what is left free.  Every result is bit-identical to the
+// one-stream order -- a tile's arithmetic does not depend on which launch computes it.  Measured (tools/ab_f32_streams.sh, one box): 8.31 -> 7.8-8.0 ms
+// at batch 256, but 4.97 -> 5.26 at 128 and 3.49 -> 4.44 at 64 (the half-sized grids no longer fill the chip): two chains from batch 192 up.
 extern "C" int rovit_vit_forward_f32(const float* images, const float* const* params, void* workspace, float* features, int batch, int depth,
                                      rovit_stream_t stream) {
   ROVIT_CHECK_ARG(images && params && workspace && features, ROVIT_ERR_NULL, "vit_forward_f32: null pointer");
   ROVIT_CHECK_ARG(batch > 0 && depth > 0, ROVIT_ERR_SHAPE, "vit_forward_f32: bad batch/depth");
-  hipStream_t st = (hipStream_t)stream;
+  hipStream_t st0 = (hipStream_t)stream;
   const int M = batch * T;
   char* ws = (char*)workspace;
   size_t o = 0;
@@ -304,26 +367,49 @@ extern "C" int rovit_vit_forward_f32(const float* images, const float* const* pa
   float* qkv = (float*)(ws + o); o += al((size_t)M * 3 * D * 4);
   float* hbuf = (float*)(ws + o);
   const float eps = 1e-6f;
-  hipLaunchKernelGGL(cls_rows_f32_kernel, dim3((batch * D + 255) / 256), dim3(256), 0, st, params[P_CLS], params[P_POS], X, batch);
-  ROVIT_CHECK_LAUNCH("cls_rows_f32_kernel");
-  RUN(gemm_f32<F_PATCH>(images, 0, params[P_PATCH_W], params[P_PATCH_B], X, D, batch * (T - 1), D, PD, params[P_POS], st));
-  const size_t attn_lds = (size_t)2 * ATP * AKS * sizeof(float);
+  const size_t attn_lds = (size_t)2 * ATR * AKS * sizeof(float);
   ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)attn_f32_mfma_kernel, attn_lds), ROVIT_ERR_LAUNCH, "vit_forward_f32: cannot raise the LDS limit");
-  for (int i = 0; i < depth; ++i) {
-    const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
-    hipLaunchKernelGGL(ln_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, st, X, bp[B_N1W], bp[B_N1B], xn, M, 1, eps);
-    ROVIT_CHECK_LAUNCH("ln_f32_kernel");
-    RUN(gemm_f32<F_NONE>(xn, D, bp[B_QKVW], bp[B_QKVB], qkv, 3 * D, M, 3 * D, D, nullptr, st));
-    hipLaunchKernelGGL(attn_f32_mfma_kernel, dim3(batch * H), dim3(ANW * 64), attn_lds, st, qkv, ao, 0.125f);
-    ROVIT_CHECK_LAUNCH("attn_f32_mfma_kernel");
-    RUN(gemm_f32<F_RESID>(ao, D, bp[B_PROJW], bp[B_PROJB], X, D, M, D, D, nullptr, st));
-    hipLaunchKernelGGL(ln_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, st, X, bp[B_N2W], bp[B_N2B], xn, M, 1, eps);
-    ROVIT_CHECK_LAUNCH("ln_f32_kernel");
-    RUN(gemm_f32<F_GELU>(xn, D, bp[B_FC1W], bp[B_FC1B], hbuf, MLP, M, MLP, D, nullptr, st));
-    RUN(gemm_f32<F_RESID>(hbuf, MLP, bp[B_FC2W], bp[B_FC2B], X, D, M, D, MLP, nullptr, st));
+  hipStream_t st1 = batch >= F32_TWO_CHAINS_FROM ? rovit_side_stream_handle() : nullptr;
+  ForkJoin* fj = st1 ? fork_join() : nullptr;
+  if (!fj) st1 = nullptr;
+  struct Half { int b0, nb; hipStream_t st; };
+  const Half halves[2] = {{0, st1 ? (batch + 1) / 2 : batch, st0}, {(batch + 1) / 2, batch / 2, st1}};
+  const int nh = st1 ? 2 : 1;
+  if (st1 && (hipEventRecord(fj->fork, st0) != hipSuccess || hipStreamWaitEvent(st1, fj->fork, 0) != hipSuccess)) {
+    rovit_set_error("vit_forward_f32: event hand-over failed");
+    return ROVIT_ERR_LAUNCH;
   }
-  // final LayerNorm on the class token of every image (row step T)
-  hipLaunchKernelGGL(ln_f32_kernel, dim3((batch + 3) / 4), dim3(256), 0, st, X, params[P_NORM_W], params[P_NORM_B], features, batch, T, eps);
-  ROVIT_CHECK_LAUNCH("ln_f32_kernel");
+  for (int hh = 0; hh < nh; ++hh) {
+    const Half& h = halves[hh];
+    hipStream_t st = h.st;
+    const size_t r0 = (size_t)h.b0 * T;                   // first token row of the half
+    const int Mh = h.nb * T;
+    float *Xh = X + r0 * D, *xnh = xn + r0 * D, *aoh = ao + r0 * D, *qkvh = qkv + r0 * 3 * D, *hh_ = hbuf + r0 * MLP;
+    hipLaunchKernelGGL(cls_rows_f32_kernel, dim3((h.nb * D + 255) / 256), dim3(256), 0, st, params[P_CLS], params[P_POS], Xh, h.nb);
+    ROVIT_CHECK_LAUNCH("cls_rows_f32_kernel");
+    RUN(gemm_f32<F_PATCH>(images + (size_t)h.b0 * 3 * 224 * 224, 0, params[P_PATCH_W], params[P_PATCH_B], Xh, D, h.nb * (T - 1), D, PD,
+                          params[P_POS], st));
+    for (int i = 0; i < depth; ++i) {
+      const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
+      hipLaunchKernelGGL(ln_f32_kernel, dim3((Mh + 3) / 4), dim3(256), 0, st, Xh, bp[B_N1W], bp[B_N1B], xnh, Mh, 1, eps);
+      ROVIT_CHECK_LAUNCH("ln_f32_kernel");
+      RUN(gemm_f32<F_NONE>(xnh, D, bp[B_QKVW], bp[B_QKVB], qkvh, 3 * D, Mh, 3 * D, D, nullptr, st));
+      hipLaunchKernelGGL(attn_f32_mfma_kernel, dim3(h.nb * H), dim3(ANW * 64), attn_lds, st, qkvh, aoh, 0.125f);
+      ROVIT_CHECK_LAUNCH("attn_f32_mfma_kernel");
+      RUN(gemm_f32<F_RESID>(aoh, D, bp[B_PROJW], bp[B_PROJB], Xh, D, Mh, D, D, nullptr, st));
+      hipLaunchKernelGGL(ln_f32_kernel, dim3((Mh + 3) / 4), dim3(256), 0, st, Xh, bp[B_N2W], bp[B_N2B], xnh, Mh, 1, eps);
+      ROVIT_CHECK_LAUNCH("ln_f32_kernel");
+      RUN(gemm_f32<F_GELU>(xnh, D, bp[B_FC1W], bp[B_FC1B], hh_, MLP, Mh, MLP, D, nullptr, st));
+      RUN(gemm_f32<F_RESID>(hh_, MLP, bp[B_FC2W], bp[B_FC2B], Xh, D, Mh, D, MLP, nullptr, st));
+    }
+    // final LayerNorm on the class token of every image (row step T)
+    hipLaunchKernelGGL(ln_f32_kernel, dim3((h.nb + 3) / 4), dim3(256), 0, st, Xh, params[P_NORM_W], params[P_NORM_B],
+                       features + (size_t)h.b0 * D, h.nb, T, eps);
+    ROVIT_CHECK_LAUNCH("ln_f32_kernel");
+  }
+  if (st1 && (hipEventRecord(fj->join, st1) != hipSuccess || hipStreamWaitEvent(st0, fj->join, 0) != hipSuccess)) {
+    rovit_set_error("vit_forward_f32: event hand-over failed");
+    return ROVIT_ERR_LAUNCH;
+  }
   return ROVIT_OK;
 }

@@ -512,6 +512,24 @@ def test_fp32_reference_precision_mode_meets_north_star_tolerances_end_to_end():
     assert m(x[:2].to(dev()))['features'].requires_grad
 
 
+def test_fp32_mode_two_half_batch_chains_equal_the_single_chain_bit_for_bit():
+    """From batch 192 up rovit_vit_forward_f32 runs the batch as two half-batch chains on two streams (csrc/vit_f32.hip).  A token row's
+    arithmetic does not depend on which launch computes it, so the features of image i must be the same bits whether it travels in a batch of
+    200 (two chains, image i in either half) or in a batch of 100 (one chain) -- also a race check on the fork / join of the side stream."""
+    sd = ref_cpu.init_rovit_state(seed=5)
+    torch.manual_seed(9)
+    m = _full_model(sd).eval()
+    m.backbone.model.precision = 'fp32'
+    x = torch.randn(200, 3, 224, 224, device=dev())
+    with torch.no_grad():
+        big = m(x)['features']
+        parts = torch.cat([m(x[:100])['features'], m(x[100:])['features']])
+        again = m(x)['features']
+    assert torch.isfinite(big).all()
+    assert torch.equal(big, parts)
+    assert torch.equal(big, again)
+
+
 def _dp_rank(rank, world, port, path, root, pkg):
     import os
     import sys

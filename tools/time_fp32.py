@@ -11,4 +11,5 @@ import bench  # noqa: E402
 
 dev = torch.device('cuda:0')
 bench._warm_clocks(dev)
-print(json.dumps({b: bench.fp32_mode(dev, b) for b in (64, 256)}))
+batches = [int(a) for a in sys.argv[1:]] or [64, 256]
+print(json.dumps({b: bench.fp32_mode(dev, b) for b in batches}))

@@ -33,25 +33,35 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 //   F_GELU : exact-erf GELU on the result          F_RESID: C += result (in place on the residual stream)
 //   F_PATCH: A is gathered from the NCHW image (row m = image b, patch p; k = c*256 + py*16 + px), the result goes to token
 //            row b*T + 1 + p with the position embedding added (timm PatchEmbed + pos_embed)
-constexpr int GBM = 128, GBN = 192, GBK = 32, GST = GBK + 4;     // GST: LDS row stride in floats
+constexpr int GBM = 128, GBK = 32, GST = GBK + 4;                // GST: LDS row stride in floats
 // (LAB: ablation bits of tools/f32_gemm_lab.hip -- 1 no global loads inside the loop, 2 no restaging at all, 4 no epilogue; the library
 // instantiates LAB = 0 only)
-template <int EPI, int LAB = 0>
-__global__ __launch_bounds__(512, 2) void gemm_f32_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W,
+// WN x NT: waves across the columns x 32-column accumulator tiles per wave; column tile BN = 32 NT WN.  2 x 3 = the 192-column tile above
+// (8 waves); 1 x 2 = a 128 x 64 tile of 4 waves, five workgroups per CU, for the N = 192 GEMMs (proj, fc2): 394 row tiles on 256 CUs leave a CU
+// with one or two 128 x 192 tiles -- the chip waits for the CUs with two -- while 1182 tiles of a third the work come 4 or 5 to a CU.
+template <int EPI, int LAB = 0, int WN = 2, int NT = 3>
+__global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 5) void gemm_f32_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W,
                                                               const float* __restrict__ bias, float* __restrict__ C, int ldc, int M, int N,
                                                               int K, const float* __restrict__ pos) {
+  constexpr int BN = 32 * NT * WN, SR = 32 * WN, QA = GBM / SR, QW = BN / SR;      // SR: rows one staging step of the workgroup covers
   __shared__ __attribute__((aligned(16))) float As[GBM * GST];
-  __shared__ __attribute__((aligned(16))) float Ws[GBN * GST];
+  __shared__ __attribute__((aligned(16))) float Ws[BN * GST];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w & 3, wn = w >> 2;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
-  // staging: thread t moves 16 bytes of row t / 8 (+ 64 per step), chunk t % 8; 2 steps for A (128 rows), 3 for W (192 rows)
+  // XCD-aware tile order (1-D grid; workgroup id L runs on XCD L % 8): the N / BN column tiles of a row tile read the same A rows, so they are
+  // given to ONE XCD, back to back -- its L2 fetches the A tile once instead of every XCD fetching it.  Row tile = 8 (slot / ncol) + xcd.
+  const int ncol = N / BN, nrow = (M + GBM - 1) / GBM;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int rt = (slot / ncol) * 8 + xcd, ct = slot - (slot / ncol) * ncol;
+  if (rt >= nrow) return;                                          // (the grid is padded to a multiple of 8 row tiles)
+  const int m0 = rt * GBM, n0 = ct * BN;
+  // staging: thread t moves 16 bytes of row t / 8 (+ SR per step), chunk t % 8; 8 waves: 2 steps for A (128 rows), 3 for W (192 rows)
   const int srow = tid >> 3, sch = tid & 7;
-  const float* a_src[2];
+  const float* a_src[QA];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    int m = m0 + srow + 64 * q;
+  for (int q = 0; q < QA; ++q) {
+    int m = m0 + srow + SR * q;
     m = m < M ? m : M - 1;                                         // clamped: rows beyond M are computed and never stored
     if (EPI == F_PATCH) {
       const int b = m / (T - 1), pch = m - b * (T - 1);
@@ -65,49 +75,49 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_mfma_kernel(const float* __re
     if (EPI == F_PATCH) return *(const float4*)(a_src[q] + ((size_t)(k >> 8) * 224 + ((k >> 4) & 15)) * 224 + (k & 15));
     return *(const float4*)(a_src[q] + k);
   };
-  auto load_w = [&](int q, int k0) -> float4 { return *(const float4*)(W + (size_t)(n0 + srow + 64 * q) * K + k0 + 4 * sch); };
-  float4 pa[2], pw[3];
+  auto load_w = [&](int q, int k0) -> float4 { return *(const float4*)(W + (size_t)(n0 + srow + SR * q) * K + k0 + 4 * sch); };
+  float4 pa[QA], pw[QW];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) pa[q] = load_a(q, 0);
+  for (int q = 0; q < QA; ++q) pa[q] = load_a(q, 0);
 #pragma unroll
-  for (int q = 0; q < 3; ++q) pw[q] = load_w(q, 0);
-  f32x16 acc[3];
+  for (int q = 0; q < QW; ++q) pw[q] = load_w(q, 0);
+  f32x16 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   for (int k0 = 0; k0 < K; k0 += GBK) {
     if (!(LAB & 2) || k0 == 0) {
     __syncthreads();                                               // every wave is done reading the previous stage
 #pragma unroll
-    for (int q = 0; q < 2; ++q) *(float4*)&As[(srow + 64 * q) * GST + 4 * sch] = pa[q];
+    for (int q = 0; q < QA; ++q) *(float4*)&As[(srow + SR * q) * GST + 4 * sch] = pa[q];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) *(float4*)&Ws[(srow + 64 * q) * GST + 4 * sch] = pw[q];
+    for (int q = 0; q < QW; ++q) *(float4*)&Ws[(srow + SR * q) * GST + 4 * sch] = pw[q];
     __syncthreads();
     }
     if (!(LAB & 3) && k0 + GBK < K) {                              // next stage: in flight while this one is computed
 #pragma unroll
-      for (int q = 0; q < 2; ++q) pa[q] = load_a(q, k0 + GBK);
+      for (int q = 0; q < QA; ++q) pa[q] = load_a(q, k0 + GBK);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) pw[q] = load_w(q, k0 + GBK);
+      for (int q = 0; q < QW; ++q) pw[q] = load_w(q, k0 + GBK);
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      float4 a4, b4[3];
+      float4 a4, b4[NT];
       if ((LAB & 8) && k0 > 0) {                                   // (lab: the matrix instructions alone, on whatever the registers hold)
         a4 = pa[0];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) b4[t] = pw[t];
+        for (int t = 0; t < NT; ++t) b4[t] = pw[t % QW];
       } else {
         a4 = *(const float4*)&As[(32 * wm + l31) * GST + 8 * c + 4 * lh];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) b4[t] = *(const float4*)&Ws[(96 * wn + 32 * t + l31) * GST + 8 * c + 4 * lh];
+        for (int t = 0; t < NT; ++t) b4[t] = *(const float4*)&Ws[(32 * NT * wn + 32 * t + l31) * GST + 8 * c + 4 * lh];
       }
       const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
       for (int sidx = 0; sidx < 4; ++sidx)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < NT; ++t) {
           const float bv[4] = {b4[t].x, b4[t].y, b4[t].z, b4[t].w};
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sidx], bv[sidx], acc[t], 0, 0, 0);
         }
@@ -115,8 +125,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_mfma_kernel(const float* __re
   }
   // accumulator tile: column n = lane & 31, row m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): a register is two 128-byte row segments
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int n = n0 + 96 * wn + 32 * t + l31;
+  for (int t = 0; t < NT; ++t) {
+    const int n = n0 + 32 * NT * wn + 32 * t + l31;
     const float bn = bias ? bias[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -315,10 +325,16 @@ __global__ __launch_bounds__(256) void cls_rows_f32_kernel(const float* __restri
   X[(size_t)b * T * D + c] = cls[c] + pos[c];
 }
 
+inline int gemm_f32_grid(int M, int N, int BN) { return ((M + GBM - 1) / GBM + 7) / 8 * 8 * (N / BN); }
+
 template <int EPI>
 int gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, const float* pos, hipStream_t st) {
-  ROVIT_CHECK_ARG(N % GBN == 0 && K % GBK == 0, ROVIT_ERR_SHAPE, "gemm_f32: N must be a multiple of %d and K of %d (got %d, %d)", GBN, GBK, N, K);
-  hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI>), dim3(N / GBN, (M + GBM - 1) / GBM), dim3(512), 0, st, A, lda, W, bias, C, ldc, M, N, K, pos);
+  // 128 x 64 tiles of 4 waves, five workgroups per CU (tools/lab/f32_gemm_lab.hip, 256 images: qkv 140 -> 114 us, fc1 170 -> 143, fc2 with the
+  // residual epilogue 175 -> 157, proj 62 -> 54 against the 128 x 192 tiles of 8 waves; same bits)
+  constexpr int WN = 1, NT = 2, BN = 32 * NT * WN;
+  ROVIT_CHECK_ARG(N % BN == 0 && K % GBK == 0, ROVIT_ERR_SHAPE, "gemm_f32: N must be a multiple of %d and K of %d (got %d, %d)", BN, GBK, N, K);
+  hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 0, WN, NT>), dim3(gemm_f32_grid(M, N, BN)), dim3(256 * WN), 0, st, A, lda, W, bias, C, ldc, M, N,
+                     K, pos);
   ROVIT_CHECK_LAUNCH("gemm_f32_mfma_kernel");
   return ROVIT_OK;
 }

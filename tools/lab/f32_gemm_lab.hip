@@ -4,6 +4,7 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -fno-vectorize -I rovit-*/csrc -I include tools/lab/f32_gemm_lab.hip \
 //         rovit-*/lib/librovit_hip.so -o /tmp/f32_gemm_lab && /tmp/f32_gemm_lab
 #include "vit_f32.hip"
+namespace { constexpr int GBN = 192; }      // the lab's LDS-DMA kernel keeps the 128 x 192 tile
 #include <cstdio>
 #include <vector>
 
@@ -146,7 +147,7 @@ template <int EPI, int LAB>
 static float time_one(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, int iters) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  dim3 grid(N / GBN, (M + GBM - 1) / GBM);
+  dim3 grid(gemm_f32_grid(M, N, 192));
   for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, LAB>), grid, dim3(512), 0, 0, A, lda, W, bias, C, ldc, M, N, K, nullptr);
   hipEventRecord(e0, 0);
   for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, LAB>), grid, dim3(512), 0, 0, A, lda, W, bias, C, ldc, M, N, K, nullptr);
@@ -166,6 +167,22 @@ static float time_dma(const float* A, int lda, const float* W, const float* bias
   for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_f32_dma_kernel<EPI, LAB>), grid, dim3(256), DMA_LDS, 0, A, lda, W, bias, C, ldc, M, N, K, nullptr);
   hipEventRecord(e0, 0);
   for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_f32_dma_kernel<EPI, LAB>), grid, dim3(256), DMA_LDS, 0, A, lda, W, bias, C, ldc, M, N, K, nullptr);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  if (hipGetLastError() != hipSuccess) printf("launch error\n");
+  return ms * 1e3f / iters;
+}
+
+template <int EPI, int WN, int NT, int LAB = 0>
+static float time_tile(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, int iters) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  dim3 grid(gemm_f32_grid(M, N, 32 * NT * WN));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, LAB, WN, NT>), grid, dim3(256 * WN), 0, 0, A, lda, W, bias, C, ldc, M, N, K, nullptr);
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, LAB, WN, NT>), grid, dim3(256 * WN), 0, 0, A, lda, W, bias, C, ldc, M, N, K, nullptr);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms = 0.f;
@@ -213,6 +230,23 @@ int main() {
     const float d6 = time_dma<F_NONE, 6>(A, s.K, W, bias, C2, s.N, M, s.N, s.K, 20);
     const float d16 = time_dma<F_NONE, 16>(A, s.K, W, bias, C2, s.N, M, s.N, s.K, 20);
     const float d20 = time_dma<F_NONE, 20>(A, s.K, W, bias, C2, s.N, M, s.N, s.K, 20);
+    {
+      hipMemset(C2, 0, (size_t)M * s.N * 4);
+      const float q12 = time_tile<F_NONE, 1, 2>(A, s.K, W, bias, C2, s.N, M, s.N, s.K, 20);
+      hipMemcpy(h2.data(), C2, (size_t)M * s.N * 4, hipMemcpyDeviceToHost);
+      size_t bad2 = 0;
+      for (size_t i = 0; i < (size_t)M * s.N; ++i) bad2 += h[i] != h2[i];
+      const float q13 = time_tile<F_NONE, 1, 3>(A, s.K, W, bias, C2, s.N, M, s.N, s.K, 20);
+      const float q11 = time_tile<F_NONE, 1, 1>(A, s.K, W, bias, C2, s.N, M, s.N, s.K, 20);
+      const float qr = time_tile<F_RESID, 2, 3>(A, s.K, W, bias, C2, s.N, M, s.N, s.K, 20);
+      const float qr12 = time_tile<F_RESID, 1, 2>(A, s.K, W, bias, C2, s.N, M, s.N, s.K, 20);
+      const float l1 = time_tile<F_NONE, 1, 2, 1>(A, s.K, W, bias, C2, s.N, M, s.N, s.K, 20);
+      const float l4 = time_tile<F_NONE, 1, 2, 4>(A, s.K, W, bias, C2, s.N, M, s.N, s.K, 20);
+      const float l6 = time_tile<F_NONE, 1, 2, 6>(A, s.K, W, bias, C2, s.N, M, s.N, s.K, 20);
+      const float l14 = time_tile<F_NONE, 1, 2, 14>(A, s.K, W, bias, C2, s.N, M, s.N, s.K, 20);
+      printf("   128 x 64 tile: no loop loads %6.1f | no epilogue %6.1f | neither, no restaging %6.1f | MFMAs alone %6.1f\n", l1, l4, l6, l14);
+      printf("   product kernel with a 128 x 64 tile (4 waves): %6.1f us, %zu results differ | 128 x 96: %6.1f | 128 x 32: %6.1f | residual epilogue: 128 x 192 %6.1f, 128 x 64 %6.1f\n", q12, bad2, q13, q11, qr, qr12);
+    }
     printf("   LDS-DMA kernel: %zu of %zu results differ from the kernel above | product %6.1f | no loop DMA %6.1f | no restaging %6.1f | no epilogue %6.1f | neither %6.1f | A stage-tiled %6.1f, and no epilogue %6.1f\n",
            bad, (size_t)M * s.N, d0, d1, d2, d4, d6, d16, d20);
   }

@@ -39,13 +39,32 @@ constexpr int GBM = 128, GBK = 32, GST = GBK + 4;                // GST: LDS row
 // WN x NT: waves across the columns x 32-column accumulator tiles per wave; column tile BN = 32 NT WN.  2 x 3 = the 192-column tile above
 // (8 waves); 1 x 2 = a 128 x 64 tile of 4 waves, five workgroups per CU, for the N = 192 GEMMs (proj, fc2): 394 row tiles on 256 CUs leave a CU
 // with one or two 128 x 192 tiles -- the chip waits for the CUs with two -- while 1182 tiles of a third the work come 4 or 5 to a CU.
-template <int EPI, int LAB = 0, int WN = 2, int NT = 3>
+// LayerNorm without a launch of its own (the model's norm1 / norm2 sit between a GEMM that completes the residual rows and a GEMM that reads
+// their normalised copy):
+//   STO: the epilogue of the GEMM that writes the rows (F_RESID, F_PATCH; N = 192 = three 64-column tiles) also writes, per row and column
+//        tile, the sum and the sum of squares of its 64 values: stats[row][ct][2] (32-lane shuffles down the accumulator registers; every
+//        slot has one writer, so the statistics are the same bits run to run);
+//   LNA: the GEMM that consumes the normalised rows (F_NONE = qkv, F_GELU = fc1; K = 192) reads the raw rows, folds the three partial sums in
+//        a fixed order (mean = sum / 192, var = sum of squares / 192 - mean^2, clamped at 0) and applies ((x - mean) rstd) gamma + beta -- the
+//        element-wise order of ln_f32_kernel -- on the staging registers before they go to LDS; gamma / beta wait in LDS (1.5 KB).
+// (One-pass variance in fp32: the rows are O(1-100) with |mean| well below the spread, relative error ~1e-7; the fp32-mode parity test holds
+// the whole model to 1e-3 against the CPU oracle and measures ~1e-5.)
+struct F32Ln {
+  const float* stats_in;      // LNA
+  const float* gamma;
+  const float* beta;
+  float* stats_out;           // STO
+  float eps;
+};
+template <int EPI, int LAB = 0, int WN = 2, int NT = 3, bool LNA = false, bool STO = false>
 __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 5) void gemm_f32_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W,
                                                               const float* __restrict__ bias, float* __restrict__ C, int ldc, int M, int N,
-                                                              int K, const float* __restrict__ pos) {
+                                                              int K, const float* __restrict__ pos, const F32Ln ln) {
   constexpr int BN = 32 * NT * WN, SR = 32 * WN, QA = GBM / SR, QW = BN / SR;      // SR: rows one staging step of the workgroup covers
   __shared__ __attribute__((aligned(16))) float As[GBM * GST];
   __shared__ __attribute__((aligned(16))) float Ws[BN * GST];
+  __shared__ __attribute__((aligned(16))) float Gs[LNA ? 2 * D : 4];               // gamma[192], beta[192]
+  __shared__ __attribute__((aligned(16))) float2 Ms[LNA ? GBM : 1];                // (mean, rstd) of the tile's rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w & 3, wn = w >> 2;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -70,6 +89,17 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 5) void gemm_f32_mfma_kerne
       a_src[q] = A + (size_t)m * lda;
     }
   }
+  if (LNA) {                                                       // (both visible behind the loop's first barrier)
+    for (int i = tid; i < 2 * D; i += 256 * WN) Gs[i] = i < D ? ln.gamma[i] : ln.beta[i - D];
+    if (tid < GBM) {
+      int m = m0 + tid;
+      m = m < M ? m : M - 1;
+      const float* sp = ln.stats_in + (size_t)m * 6;
+      const float mean = ((sp[0] + sp[2]) + sp[4]) * (1.f / D);
+      const float var = fmaxf(((sp[1] + sp[3]) + sp[5]) * (1.f / D) - mean * mean, 0.f);
+      Ms[tid] = make_float2(mean, 1.f / sqrtf(var + ln.eps));
+    }
+  }
   auto load_a = [&](int q, int k0) -> float4 {
     const int k = k0 + 4 * sch;
     if (EPI == F_PATCH) return *(const float4*)(a_src[q] + ((size_t)(k >> 8) * 224 + ((k >> 4) & 15)) * 224 + (k & 15));
@@ -89,6 +119,17 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 5) void gemm_f32_mfma_kerne
   for (int k0 = 0; k0 < K; k0 += GBK) {
     if (!(LAB & 2) || k0 == 0) {
     __syncthreads();                                               // every wave is done reading the previous stage
+    if (LNA) {
+      const float4 g4 = *(const float4*)&Gs[k0 + 4 * sch], b4 = *(const float4*)&Gs[D + k0 + 4 * sch];
+#pragma unroll
+      for (int q = 0; q < QA; ++q) {
+        const float2 mr = Ms[srow + SR * q];
+        pa[q].x = (pa[q].x - mr.x) * mr.y * g4.x + b4.x;
+        pa[q].y = (pa[q].y - mr.x) * mr.y * g4.y + b4.y;
+        pa[q].z = (pa[q].z - mr.x) * mr.y * g4.z + b4.z;
+        pa[q].w = (pa[q].w - mr.x) * mr.y * g4.w + b4.w;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < QA; ++q) *(float4*)&As[(srow + SR * q) * GST + 4 * sch] = pa[q];
 #pragma unroll
@@ -124,26 +165,52 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 5) void gemm_f32_mfma_kerne
     }
   }
   // accumulator tile: column n = lane & 31, row m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): a register is two 128-byte row segments
+  float bn[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int n = n0 + 32 * NT * wn + 32 * t + l31;
-    const float bn = bias ? bias[n] : 0.f;
+  for (int t = 0; t < NT; ++t) bn[t] = bias ? bias[n0 + 32 * NT * wn + 32 * t + l31] : 0.f;
+  auto out_row = [&](int m) -> size_t {                             // output row of tile row m (rows beyond M: computed, never stored)
+    size_t orow = (size_t)(m < M ? m : M - 1);
+    if (EPI == F_PATCH) {
+      const int b = (int)orow / (T - 1), pch = (int)orow - b * (T - 1);
+      orow = (size_t)b * T + 1 + pch;
+    }
+    return orow;
+  };
+  float st[STO ? 32 : 1];                                           // st[2 r + j]: this lane's part of row r's sum (j = 0) / sum of squares (1)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m >= M) continue;
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    float s1 = 0.f, s2 = 0.f;
+    const size_t orow = out_row(m);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = n0 + 32 * NT * wn + 32 * t + l31;
       if ((LAB & 4) && acc[t][r] != 12345.678f) continue;
-      float v = acc[t][r] + bn;
+      float v = acc[t][r] + bn[t];
       if (EPI == F_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));      // exact-erf GELU (timm default)
-      if (EPI == F_PATCH) {
-        const int b = m / (T - 1), pch = m - b * (T - 1);
-        C[((size_t)b * T + 1 + pch) * ldc + n] = v + pos[(size_t)(1 + pch) * N + n];
-      } else if (EPI == F_RESID) {
-        C[(size_t)m * ldc + n] += v;
-      } else {
-        C[(size_t)m * ldc + n] = v;
+      if (EPI == F_PATCH) v += pos[(orow % T) * N + n];
+      if (EPI == F_RESID) v += C[orow * ldc + n];
+      if (m < M) C[orow * ldc + n] = v;
+      s1 += v;
+      s2 += v * v;
+    }
+    if (STO) { st[2 * r] = s1; st[2 * r + 1] = s2; }
+  }
+  if (STO) {
+    // 32 values per lane, to be summed over the 32 lanes of a lane half (the wave holds the rows' 64 values of column tile ct: WN = 1):
+    // halving butterfly -- at distance o a lane keeps the half of its values whose index has bit o set like its own lane number and adds
+    // the partner's copy of that half; 16 + 8 + 4 + 2 + 1 exchanges instead of 5 x 32, and lane l ends with the total of value l.
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) {
+      const bool up = (l31 & o) != 0;
+#pragma unroll
+      for (int i = 0; i < o; ++i) {
+        const float keep = up ? st[i + o] : st[i], send = up ? st[i] : st[i + o];
+        st[i] = keep + __shfl_xor(send, o);
       }
     }
+    const int r = l31 >> 1, m = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (m < M) ln.stats_out[out_row(m) * 6 + ct * 2 + (l31 & 1)] = st[0];
   }
 }
 
@@ -318,23 +385,35 @@ __global__ __launch_bounds__(ANW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))
   }
 }
 
-__global__ __launch_bounds__(256) void cls_rows_f32_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ X, int B) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= B * D) return;
-  const int b = e / D, c = e - b * D;
-  X[(size_t)b * T * D + c] = cls[c] + pos[c];
+// the class-token row of every image (cls + pos[0]) and its LayerNorm statistics (slot 0 of the row's three; see F32Ln): one wave per image
+__global__ __launch_bounds__(256) void cls_rows_f32_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ X,
+                                                          float* __restrict__ stats, int B) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float v = cls[lane + 64 * i] + pos[lane + 64 * i];
+    X[(size_t)b * T * D + lane + 64 * i] = v;
+    s1 += v; s2 += v * v;
+  }
+  s1 = wave_sum64(s1); s2 = wave_sum64(s2);
+  if (lane < 6) stats[(size_t)b * T * 6 + lane] = lane == 0 ? s1 : lane == 1 ? s2 : 0.f;
 }
 
 inline int gemm_f32_grid(int M, int N, int BN) { return ((M + GBM - 1) / GBM + 7) / 8 * 8 * (N / BN); }
 
-template <int EPI>
-int gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, const float* pos, hipStream_t st) {
+template <int EPI, bool LNA = false, bool STO = false>
+int gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, const float* pos, hipStream_t st,
+             const F32Ln ln = F32Ln{nullptr, nullptr, nullptr, nullptr, 0.f}) {
   // 128 x 64 tiles of 4 waves, five workgroups per CU (tools/lab/f32_gemm_lab.hip, 256 images: qkv 140 -> 114 us, fc1 170 -> 143, fc2 with the
   // residual epilogue 175 -> 157, proj 62 -> 54 against the 128 x 192 tiles of 8 waves; same bits)
   constexpr int WN = 1, NT = 2, BN = 32 * NT * WN;
   ROVIT_CHECK_ARG(N % BN == 0 && K % GBK == 0, ROVIT_ERR_SHAPE, "gemm_f32: N must be a multiple of %d and K of %d (got %d, %d)", BN, GBK, N, K);
-  hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 0, WN, NT>), dim3(gemm_f32_grid(M, N, BN)), dim3(256 * WN), 0, st, A, lda, W, bias, C, ldc, M, N,
-                     K, pos);
+  ROVIT_CHECK_ARG((!LNA || (K == D && ln.stats_in && ln.gamma && ln.beta)) && (!STO || (N == D && ln.stats_out)), ROVIT_ERR_SHAPE,
+                  "gemm_f32: the LayerNorm hooks need K = %d (consumer) / N = %d (producer)", D, D);
+  hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 0, WN, NT, LNA, STO>), dim3(gemm_f32_grid(M, N, BN)), dim3(256 * WN), 0, st, A, lda, W, bias, C, ldc,
+                     M, N, K, pos, ln);
   ROVIT_CHECK_LAUNCH("gemm_f32_mfma_kernel");
   return ROVIT_OK;
 }
@@ -356,7 +435,7 @@ ForkJoin* fork_join() {
 
 }  // namespace
 
-// workspace: X (M,192) + xn (M,192) + qkv (M,576) + o (M,192) + h (M,768), all fp32, M = batch * 197
+// workspace: X (M,192) + row statistics (M,6; in a (M,192) slot) + qkv (M,576) + o (M,192) + h (M,768), all fp32, M = batch * 197
 extern "C" size_t rovit_vit_f32_workspace_bytes(int batch) {
   const size_t M = (size_t)batch * T;
   return al(M * D * 4) * 3 + al(M * 3 * D * 4) + al(M * MLP * 4);
@@ -378,7 +457,7 @@ extern "C" int rovit_vit_forward_f32(const float* images, const float* const* pa
   char* ws = (char*)workspace;
   size_t o = 0;
   float* X = (float*)(ws + o); o += al((size_t)M * D * 4);
-  float* xn = (float*)(ws + o); o += al((size_t)M * D * 4);
+  float* stats = (float*)(ws + o); o += al((size_t)M * D * 4);      // (M, 3, 2) row statistics; the slot once held the normalised rows
   float* ao = (float*)(ws + o); o += al((size_t)M * D * 4);
   float* qkv = (float*)(ws + o); o += al((size_t)M * 3 * D * 4);
   float* hbuf = (float*)(ws + o);
@@ -400,23 +479,21 @@ extern "C" int rovit_vit_forward_f32(const float* images, const float* const* pa
     hipStream_t st = h.st;
     const size_t r0 = (size_t)h.b0 * T;                   // first token row of the half
     const int Mh = h.nb * T;
-    float *Xh = X + r0 * D, *xnh = xn + r0 * D, *aoh = ao + r0 * D, *qkvh = qkv + r0 * 3 * D, *hh_ = hbuf + r0 * MLP;
-    hipLaunchKernelGGL(cls_rows_f32_kernel, dim3((h.nb * D + 255) / 256), dim3(256), 0, st, params[P_CLS], params[P_POS], Xh, h.nb);
+    float *Xh = X + r0 * D, *sth = stats + r0 * 6, *aoh = ao + r0 * D, *qkvh = qkv + r0 * 3 * D, *hh_ = hbuf + r0 * MLP;
+    const F32Ln sto{nullptr, nullptr, nullptr, sth, eps};           // producers: the row statistics go to sth
+    hipLaunchKernelGGL(cls_rows_f32_kernel, dim3((h.nb + 3) / 4), dim3(256), 0, st, params[P_CLS], params[P_POS], Xh, sth, h.nb);
     ROVIT_CHECK_LAUNCH("cls_rows_f32_kernel");
-    RUN(gemm_f32<F_PATCH>(images + (size_t)h.b0 * 3 * 224 * 224, 0, params[P_PATCH_W], params[P_PATCH_B], Xh, D, h.nb * (T - 1), D, PD,
-                          params[P_POS], st));
+    RUN((gemm_f32<F_PATCH, false, true>(images + (size_t)h.b0 * 3 * 224 * 224, 0, params[P_PATCH_W], params[P_PATCH_B], Xh, D, h.nb * (T - 1), D, PD,
+                                        params[P_POS], st, sto)));
     for (int i = 0; i < depth; ++i) {
       const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
-      hipLaunchKernelGGL(ln_f32_kernel, dim3((Mh + 3) / 4), dim3(256), 0, st, Xh, bp[B_N1W], bp[B_N1B], xnh, Mh, 1, eps);
-      ROVIT_CHECK_LAUNCH("ln_f32_kernel");
-      RUN(gemm_f32<F_NONE>(xnh, D, bp[B_QKVW], bp[B_QKVB], qkvh, 3 * D, Mh, 3 * D, D, nullptr, st));
+      // norm1 / norm2 have no launch: statistics from the producer's epilogue, normalisation on the consumer's staging registers (F32Ln)
+      RUN((gemm_f32<F_NONE, true>(Xh, D, bp[B_QKVW], bp[B_QKVB], qkvh, 3 * D, Mh, 3 * D, D, nullptr, st, F32Ln{sth, bp[B_N1W], bp[B_N1B], nullptr, eps})));
       hipLaunchKernelGGL(attn_f32_mfma_kernel, dim3(h.nb * H), dim3(ANW * 64), attn_lds, st, qkvh, aoh, 0.125f);
       ROVIT_CHECK_LAUNCH("attn_f32_mfma_kernel");
-      RUN(gemm_f32<F_RESID>(aoh, D, bp[B_PROJW], bp[B_PROJB], Xh, D, Mh, D, D, nullptr, st));
-      hipLaunchKernelGGL(ln_f32_kernel, dim3((Mh + 3) / 4), dim3(256), 0, st, Xh, bp[B_N2W], bp[B_N2B], xnh, Mh, 1, eps);
-      ROVIT_CHECK_LAUNCH("ln_f32_kernel");
-      RUN(gemm_f32<F_GELU>(xnh, D, bp[B_FC1W], bp[B_FC1B], hh_, MLP, Mh, MLP, D, nullptr, st));
-      RUN(gemm_f32<F_RESID>(hh_, MLP, bp[B_FC2W], bp[B_FC2B], Xh, D, Mh, D, MLP, nullptr, st));
+      RUN((gemm_f32<F_RESID, false, true>(aoh, D, bp[B_PROJW], bp[B_PROJB], Xh, D, Mh, D, D, nullptr, st, sto)));
+      RUN((gemm_f32<F_GELU, true>(Xh, D, bp[B_FC1W], bp[B_FC1B], hh_, MLP, Mh, MLP, D, nullptr, st, F32Ln{sth, bp[B_N2W], bp[B_N2B], nullptr, eps})));
+      RUN((gemm_f32<F_RESID, false, true>(hh_, MLP, bp[B_FC2W], bp[B_FC2B], Xh, D, Mh, D, MLP, nullptr, st, sto)));
     }
     // final LayerNorm on the class token of every image (row step T)
     hipLaunchKernelGGL(ln_f32_kernel, dim3((h.nb + 3) / 4), dim3(256), 0, st, Xh, params[P_NORM_W], params[P_NORM_B],

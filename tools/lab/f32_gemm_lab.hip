@@ -148,9 +148,9 @@ static float time_one(const float* A, int lda, const float* W, const float* bias
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   dim3 grid(gemm_f32_grid(M, N, 192));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, LAB>), grid, dim3(512), 0, 0, A, lda, W, bias, C, ldc, M, N, K, nullptr);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, LAB>), grid, dim3(512), 0, 0, A, lda, W, bias, C, ldc, M, N, K, nullptr, F32Ln{nullptr, nullptr, nullptr, nullptr, 0.f});
   hipEventRecord(e0, 0);
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, LAB>), grid, dim3(512), 0, 0, A, lda, W, bias, C, ldc, M, N, K, nullptr);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, LAB>), grid, dim3(512), 0, 0, A, lda, W, bias, C, ldc, M, N, K, nullptr, F32Ln{nullptr, nullptr, nullptr, nullptr, 0.f});
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms = 0.f;
@@ -180,9 +180,9 @@ static float time_tile(const float* A, int lda, const float* W, const float* bia
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   dim3 grid(gemm_f32_grid(M, N, 32 * NT * WN));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, LAB, WN, NT>), grid, dim3(256 * WN), 0, 0, A, lda, W, bias, C, ldc, M, N, K, nullptr);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, LAB, WN, NT>), grid, dim3(256 * WN), 0, 0, A, lda, W, bias, C, ldc, M, N, K, nullptr, F32Ln{nullptr, nullptr, nullptr, nullptr, 0.f});
   hipEventRecord(e0, 0);
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, LAB, WN, NT>), grid, dim3(256 * WN), 0, 0, A, lda, W, bias, C, ldc, M, N, K, nullptr);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, LAB, WN, NT>), grid, dim3(256 * WN), 0, 0, A, lda, W, bias, C, ldc, M, N, K, nullptr, F32Ln{nullptr, nullptr, nullptr, nullptr, 0.f});
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms = 0.f;

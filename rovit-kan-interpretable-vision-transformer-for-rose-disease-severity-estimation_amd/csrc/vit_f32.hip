@@ -232,52 +232,56 @@ __global__ __launch_bounds__(256) void ln_f32_kernel(const float* __restrict__ x
   for (int i = 0; i < 3; ++i) y[(size_t)row * D + lane + 64 * i] = v[i] * rstd * gamma[lane + 64 * i] + beta[lane + 64 * i];
 }
 
-// softmax(q k^T * scale) v for one (image, head) on the fp32 matrix cores: K and V (200 rows x 64 fp32, zero beyond T, rows padded to
-// 68 floats) in LDS, wave w owns queries 32w .. 32w + 31.  (The seventh key tile reads K rows 200 .. 223 out of the V area: whatever lies
-// there, those scores are REPLACED by -inf before the softmax, and a row of S^T depends on its own K row only.  V needs rows up to 199:
-// the last contraction steps pair key 192 + j with 196 + j.  200 rows keep the tile pair at 106 KB so that a GEMM workgroup of the other
-// half-batch (45 KB) fits on the same CU.)
+// softmax(q k^T * scale) v on the fp32 matrix cores.  Workgroup = 4 waves = HALF of an (image, head): wave w of half g owns queries
+// 32 (4 g + w) .. + 31 (seven query tiles: half 0 has four, half 1 three and an idle wave).  ONE LDS tile (224 zero-padded rows x 64 fp32, rows
+// padded to 68 floats; 60.9 KB) holds K for the first product and V for the second, so TWO workgroups share a CU and one's loads, softmax
+// and output run beside the other's matrix phases (a workgroup per (image, head) with K and V both resident -- 7 waves, 106 KB, one per
+// CU, every phase exposed -- took 113 us per 256-image block; the halves read K and V twice from L2, 2 x 39 MB).
 //   S^T[key][q] = K Q^T: A = K rows from LDS (one 16-byte read feeds 4 MFMAs), B = the wave's scaled Q rows in 32 registers (lane half h
 //   holds d = 32h + s for step s -- the same map on the K side); seven 32 x 32 accumulator tiles = the whole 224-key column block.
 //   softmax down the accumulator registers of a lane (+ one exchange with lane ^ 32), exact expf, masked beyond T.
 //   O^T[d][q] = V^T P^T: the probabilities ARE the B operand as they stand -- register r of tile kt holds key 32kt + (r&3) + 8(r>>2) + 4h,
 //   so step r contracts over exactly those two keys and the A operand is V[that key][32 dt + lane & 31] (a 128-byte row read per half).
-// Output through a wave-private LDS patch (in the K tile, free behind a barrier) so that rows leave as 256-byte runs.
-constexpr int AKS = HD + 4, ATP = 224, ATR = 200, ANW = 7;
-__global__ __launch_bounds__(ANW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void attn_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, float scale) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* Ks = sm;
-  float* Vs = sm + ATR * AKS;
-  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+// Output through a wave-private LDS patch (in the tile, free behind a barrier) so that rows leave as 256-byte runs.
+constexpr int AKS = HD + 4, ATP = 224, ANW = 4, ACH = ATP * 16 / (ANW * 64);       // ACH: 16-byte chunks of the tile per thread (14)
+constexpr size_t ATTN_LDS = (size_t)ATP * AKS * sizeof(float);
+__global__ __launch_bounds__(ANW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float KV[];
+  const int bh = blockIdx.x >> 1, half = blockIdx.x & 1, b = bh / H, h = bh - b * H;
   const int ld = 3 * D;
   const float* base = qkv + (size_t)b * T * ld + h * HD;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // K goes to LDS now; V is only REQUESTED here (8 x 16 bytes per thread in registers) and written behind the S products, so its
-  // latency hides under the first matrix phase (one workgroup per CU: nothing else would cover it)
-  static_assert(ATP * 16 == 8 * ANW * 64, "8 chunks of a tile per thread");
-  const int q0 = 32 * w;
-  const bool active = q0 < T;                           // wave-uniform; inactive waves only keep the barriers company
+  static_assert(ACH * ANW * 64 == ATP * 16, "whole chunks per thread");
+  const int q0 = 32 * (4 * half + w);
+  const bool active = q0 < T;                           // wave-uniform; the idle wave of half 1 only stages and keeps the barriers company
   float4 qraw[8];                                       // the wave's 32 query rows: lane half h holds d = 32h .. 32h + 31 of row q0 + lane & 31
   {
     const int qr = q0 + l31, qc = qr < T ? qr : T - 1;
 #pragma unroll
     for (int i = 0; i < 8; ++i) qraw[i] = *(const float4*)(base + (size_t)qc * ld + 32 * lh + 4 * i);
   }
-  float4 vreg[8], kreg[8];
+  // global -> registers -> LDS of K (col = D) or V (col = 2 D), rows beyond T zero; NB chunks per batch are in flight together
+  auto stage = [&](int col) {
+    constexpr int NB = ACH / 2;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {                         // all 24 requests of the thread are in flight before the first one is waited for
-    const int e = tid + i * ANW * 64, r = e >> 4, c = e & 15, rc = r < T ? r : T - 1;
-    kreg[i] = *(const float4*)(base + (size_t)rc * ld + D + 4 * c);
-    vreg[i] = *(const float4*)(base + (size_t)rc * ld + 2 * D + 4 * c);
-  }
-  __builtin_amdgcn_sched_barrier(0);
+    for (int i0 = 0; i0 < ACH; i0 += NB) {
+      float4 reg[NB];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int e = tid + i * ANW * 64, r = e >> 4, c = e & 15;
-    if (r >= T) { kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f); vreg[i] = kreg[i]; }
-    if (r < ATR) *(float4*)&Ks[r * AKS + 4 * c] = kreg[i];
-  }
+      for (int i = 0; i < NB; ++i) {
+        const int e = tid + (i0 + i) * ANW * 64, r = e >> 4, c = e & 15, rc = r < T ? r : T - 1;
+        reg[i] = *(const float4*)(base + (size_t)rc * ld + col + 4 * c);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int e = tid + (i0 + i) * ANW * 64, r = e >> 4, c = e & 15;
+        if (r >= T) reg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        *(float4*)&KV[r * AKS + 4 * c] = reg[i];
+      }
+    }
+  };
+  stage(D);
   float qv[32];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(ANW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))
   float inv_l = 0.f;
   if (active) {
     // the K fragments of step (kt, c) + 2 are requested before the four MFMAs of step (kt, c) are issued (three register sets)
-    const float* krow = &Ks[l31 * AKS + 32 * lh];
+    const float* krow = &KV[l31 * AKS + 32 * lh];
     float4 kf[3];
     kf[0] = *(const float4*)krow;
     kf[1] = *(const float4*)(krow + 4);
@@ -332,11 +336,8 @@ __global__ __launch_bounds__(ANW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))
     l += __shfl_xor(l, 32);
     inv_l = 1.f / l;
   }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int e = tid + i * ANW * 64;
-    if ((e >> 4) < ATR) *(float4*)&Vs[(e >> 4) * AKS + 4 * (e & 15)] = vreg[i];
-  }
+  __syncthreads();                                      // every wave is done with K: V takes the tile
+  stage(2 * D);
   __syncthreads();
   f32x16 o[2];
 #pragma unroll
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(ANW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))
     // steps 100 .. 111 are padding (T = 197).  The V operands of step s + 3 are requested before the two MFMAs of step s are issued.
     constexpr int NSTEP = 100;
     static_assert(T == 197, "step count of the P V product");
-    const float* vbase = &Vs[4 * lh * AKS + l31];
+    const float* vbase = &KV[4 * lh * AKS + l31];
     float va[4], vb[4];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -368,8 +369,8 @@ __global__ __launch_bounds__(ANW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  __syncthreads();                                      // nobody reads K or V any more: the area becomes seven 32 x 68 output patches
-  float* patch = Ks + w * 32 * AKS;
+  __syncthreads();                                      // nobody reads V any more: the tile becomes four 32 x 68 output patches
+  float* patch = KV + w * 32 * AKS;
   if (active) {
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -462,8 +463,7 @@ extern "C" int rovit_vit_forward_f32(const float* images, const float* const* pa
   float* qkv = (float*)(ws + o); o += al((size_t)M * 3 * D * 4);
   float* hbuf = (float*)(ws + o);
   const float eps = 1e-6f;
-  const size_t attn_lds = (size_t)2 * ATR * AKS * sizeof(float);
-  ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)attn_f32_mfma_kernel, attn_lds), ROVIT_ERR_LAUNCH, "vit_forward_f32: cannot raise the LDS limit");
+  ROVIT_CHECK_ARG(rovit_set_max_lds((const void*)attn_f32_mfma_kernel, ATTN_LDS), ROVIT_ERR_LAUNCH, "vit_forward_f32: cannot raise the LDS limit");
   hipStream_t st1 = batch >= F32_TWO_CHAINS_FROM ? rovit_side_stream_handle() : nullptr;
   ForkJoin* fj = st1 ? fork_join() : nullptr;
   if (!fj) st1 = nullptr;
@@ -489,7 +489,7 @@ extern "C" int rovit_vit_forward_f32(const float* images, const float* const* pa
       const float* const* bp = params + P_BLOCK0 + B_COUNT * i;
       // norm1 / norm2 have no launch: statistics from the producer's epilogue, normalisation on the consumer's staging registers (F32Ln)
       RUN((gemm_f32<F_NONE, true>(Xh, D, bp[B_QKVW], bp[B_QKVB], qkvh, 3 * D, Mh, 3 * D, D, nullptr, st, F32Ln{sth, bp[B_N1W], bp[B_N1B], nullptr, eps})));
-      hipLaunchKernelGGL(attn_f32_mfma_kernel, dim3(h.nb * H), dim3(ANW * 64), attn_lds, st, qkvh, aoh, 0.125f);
+      hipLaunchKernelGGL(attn_f32_mfma_kernel, dim3(h.nb * H * 2), dim3(ANW * 64), ATTN_LDS, st, qkvh, aoh, 0.125f);
       ROVIT_CHECK_LAUNCH("attn_f32_mfma_kernel");
       RUN((gemm_f32<F_RESID, false, true>(aoh, D, bp[B_PROJW], bp[B_PROJB], Xh, D, Mh, D, D, nullptr, st, sto)));
       RUN((gemm_f32<F_GELU, true>(Xh, D, bp[B_FC1W], bp[B_FC1B], hh_, MLP, Mh, MLP, D, nullptr, st, F32Ln{sth, bp[B_N2W], bp[B_N2B], nullptr, eps})));

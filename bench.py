@@ -328,7 +328,7 @@ def fp32_mode(dev, batch=256, iters=5):
     tf = FWD_FLOP_PER_IMG * batch / (ms * 1e-3) / 1e12
     return {'ms_per_forward': round(ms, 3), 'images_per_sec': round(batch / (ms * 1e-3), 1), 'batch': batch,
             'fp32_tflops': round(tf, 1), 'frac_of_fp32_matrix_peak': round(tf / FP32_PEAK_TFLOPS, 4),
-            'kernels': 'gemm_f32_mfma_kernel (128x192 tiles), attn_f32_mfma_kernel: v_mfma_f32_32x32x2_f32, exact fp32 FMA chains; two half-batch chains on two streams from batch 192'}
+            'kernels': 'gemm_f32_mfma_kernel (128x64 tiles, five workgroups per CU, LayerNorms folded into the neighbouring GEMMs), attn_f32_mfma_kernel (half an (image, head) per workgroup, two per CU): v_mfma_f32_32x32x2_f32, exact fp32 FMA chains; two half-batch chains on two streams from batch 192'}
 
 
 def kan_roofline(dev, iters=30):

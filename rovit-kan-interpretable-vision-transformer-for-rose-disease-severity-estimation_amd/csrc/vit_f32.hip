@@ -7,8 +7,8 @@
 // SURVEY.md section 2, reached from /root/reference/models/backbone.py:12-25) entirely in fp32 on the GPU, so the end-to-end
 // parity statement can be made at fp32 tolerance.  Round 4: the GEMMs and the two attention products run on the fp32 matrix
 // cores (v_mfma_f32_32x32x2_f32: fp32 operands, every product and sum an exact fp32 FMA chain in a fixed k order, no bf16
-// anywhere -- MI355X_MICROARCH.md "FP32-input MFMA"), 157 TFLOP/s peak = 1/16 of the bf16 rate; the round-2 VALU tiles ran at
-// 41 TFLOP/s (15.5 ms per 256 images).
+// anywhere -- MI355X_MICROARCH.md "FP32-input MFMA"), 157 TFLOP/s peak = 1/16 of the bf16 rate: 6.90 ms per 256 images = 93 TFLOP/s (the
+// round-2 VALU tiles ran at 41 TFLOP/s, 15.5 ms).
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -22,11 +22,13 @@ enum { F_NONE = 0, F_GELU = 1, F_RESID = 2, F_PATCH = 3 };
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// C[M,N] = A[M,K] W[N,K]^T + bias on the fp32 matrix cores.  Workgroup = 8 waves = a 128 x 192 output tile (every N of the model
-// is a multiple of 192), wave (wm, wn) = rows 32 wm .. + 31 x columns 96 wn .. + 95 = three 32 x 32 accumulator tiles (48 registers).
-// K walks in steps of 32 through ONE LDS stage (A 128 x 32 and W 192 x 32 floats, rows padded to 36 floats: ds_read_b128 of 16
-// rows x 16 bytes is conflict-free); the next stage's 40 KB are requested from global memory before the stage is computed and
-// written behind it, so two workgroups per CU (46 KB, <= 128 VGPRs) hide each other's barriers.
+// C[M,N] = A[M,K] W[N,K]^T + bias on the fp32 matrix cores.  Workgroup = 4 WN waves = a 128 x (32 NT WN) output tile, wave (wm, wn) =
+// rows 32 wm .. + 31 x NT accumulator tiles of 32 x 32.  The library runs WN = 1, NT = 2: a 128 x 64 tile of 4 waves, five workgroups per CU
+// (27.6 KB of LDS, 88-96 VGPRs) -- small workgroups in different phases hide each other's loads, barriers and epilogues, and the tile count
+// no longer leaves a third of the CUs with twice the work (tools/lab/f32_gemm_lab.hip times it against WN = 2, NT = 3, the 128 x 192 tile
+// of 8 waves it replaced: qkv 140 -> 114 us, fc1 170 -> 143, fc2 175 -> 157 per 256 images, same bits).
+// K walks in steps of 32 through ONE LDS stage (A 128 x 32 and W BN x 32 floats, rows padded to 36 floats: ds_read_b128 of 16
+// rows x 16 bytes is conflict-free); the next stage is requested from global memory before the stage is computed and written behind it.
 // Operand order inside a 32-deep stage: a lane holds 4 consecutive k of its row from one 16-byte read and feeds them to 4
 // MFMAs; the lane half h = lane >> 5 takes k = 8c + 4h + s in MFMA s of chunk c -- the SAME map for A and for W, so the products pair
 // up correctly and the summation order (k = 8c + s, then 8c + 4 + s, for s, then c, then stage) is fixed: bit-reproducible.
@@ -36,9 +38,6 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 constexpr int GBM = 128, GBK = 32, GST = GBK + 4;                // GST: LDS row stride in floats
 // (LAB: ablation bits of tools/f32_gemm_lab.hip -- 1 no global loads inside the loop, 2 no restaging at all, 4 no epilogue; the library
 // instantiates LAB = 0 only)
-// WN x NT: waves across the columns x 32-column accumulator tiles per wave; column tile BN = 32 NT WN.  2 x 3 = the 192-column tile above
-// (8 waves); 1 x 2 = a 128 x 64 tile of 4 waves, five workgroups per CU, for the N = 192 GEMMs (proj, fc2): 394 row tiles on 256 CUs leave a CU
-// with one or two 128 x 192 tiles -- the chip waits for the CUs with two -- while 1182 tiles of a third the work come 4 or 5 to a CU.
 // LayerNorm without a launch of its own (the model's norm1 / norm2 sit between a GEMM that completes the residual rows and a GEMM that reads
 // their normalised copy):
 //   STO: the epilogue of the GEMM that writes the rows (F_RESID, F_PATCH; N = 192 = three 64-column tiles) also writes, per row and column

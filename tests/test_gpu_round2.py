@@ -530,6 +530,50 @@ def test_fp32_mode_two_half_batch_chains_equal_the_single_chain_bit_for_bit():
     assert torch.equal(big, again)
 
 
+def test_fp32_mode_shares_the_side_stream_with_training_steps_without_changing_a_bit():
+    """The two-chain fp32 forward borrows the library's side stream, which the training backward uses for its weight-gradient launches.
+    Alternating the two (no synchronisation in between other than stream order) must leave both unchanged: the fp32 features are the
+    same bits before, between and after training steps of ANOTHER model instance, and that model's loss trajectory equals the one it
+    takes without the fp32 calls in between."""
+    from rovit_hip.losses import JointLoss
+    from rovit_hip.optim import RoViTAdamW
+    sd = ref_cpu.init_rovit_state(seed=5)
+    torch.manual_seed(13)
+    ev = _full_model(sd).eval()
+    ev.backbone.model.precision = 'fp32'
+    x = torch.randn(200, 3, 224, 224, device=dev())
+    xb = torch.randn(16, 3, 224, 224, device=dev())
+    cls_t = torch.randint(0, 4, (16,), device=dev())
+    sev_t = torch.randint(0, 4, (16,), device=dev())
+
+    def train_losses(interleave):
+        torch.manual_seed(21)
+        m = _full_model(sd).train()
+        m.curriculum_stage = 4
+        opt = RoViTAdamW(m, lr=1e-3)
+        loss_fn = JointLoss(1.0, 0.5, 0.5, 2.0)
+        out, feats = [], []
+        for _ in range(3):
+            if interleave:
+                with torch.no_grad():
+                    feats.append(ev(x)['features'])
+            opt.zero_grad()
+            loss = loss_fn(m(xb), cls_t, sev_t, 4)['total_loss']
+            loss.backward()
+            opt.step()
+            out.append(loss.detach())
+        if interleave:
+            with torch.no_grad():
+                feats.append(ev(x)['features'])
+        return torch.stack(out).cpu(), feats
+
+    plain, _ = train_losses(False)
+    mixed, feats = train_losses(True)
+    assert torch.equal(plain, mixed), (plain, mixed)
+    for f in feats[1:]:
+        assert torch.equal(f, feats[0])
+
+
 def _dp_rank(rank, world, port, path, root, pkg):
     import os
     import sys

@@ -202,7 +202,9 @@ int rovit_vit_backward(const float* images, const float* d_features, const float
 /* fp32 reference-precision forward (inference only; parity / evaluation mode, not the fast path): the same arithmetic
  * with every operand, product and sum in fp32 -- the mode in which BASELINE.json's "logits/severity within 1e-3 (fp32),
  * class argmax bit-exact" is checked end to end.  params: the ORIGINAL fp32 parameters (no prepared weights);
- * workspace: rovit_vit_f32_workspace_bytes(batch) bytes. */
+ * workspace: rovit_vit_f32_workspace_bytes(batch) bytes.  From batch 192 up the call runs the batch as two half-batch
+ * chains, one on `stream` and one on the library's side stream (forked from and joined back into `stream`: to the caller it
+ * is one stream-ordered call); the result does not depend on the batch an image travels in. */
 size_t rovit_vit_f32_workspace_bytes(int batch);
 int rovit_vit_forward_f32(const float* images, const float* const* params, void* workspace, float* features, int batch, int depth,
                           rovit_stream_t stream);

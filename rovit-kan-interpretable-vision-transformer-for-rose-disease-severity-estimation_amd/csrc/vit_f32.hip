@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256) void ln_f32_kernel(const float* __restrict__ x
 //   O^T[d][q] = V^T P^T: the probabilities ARE the B operand as they stand -- register r of tile kt holds key 32kt + (r&3) + 8(r>>2) + 4h,
 //   so step r contracts over exactly those two keys and the A operand is V[that key][32 dt + lane & 31] (a 128-byte row read per half).
 // Output through a wave-private LDS patch (in the tile, free behind a barrier) so that rows leave as 256-byte runs.
+// (Three workgroups per CU -- a 200-row tile, 54.4 KB -- need the kernel under 168 VGPRs: 152 bytes of scratch, 126 us instead of 105.)
 constexpr int AKS = HD + 4, ATP = 224, ANW = 4, ACH = ATP * 16 / (ANW * 64);       // ACH: 16-byte chunks of the tile per thread (14)
 constexpr size_t ATTN_LDS = (size_t)ATP * AKS * sizeof(float);
 __global__ __launch_bounds__(ANW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, float scale) {

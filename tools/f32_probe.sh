@@ -33,4 +33,26 @@ for k, c in sorted(acc.items()):
     print(k[0], 'grid', k[1], ' '.join('%s=%.3g' % (n, sum(v) / len(v)) for n, v in sorted(c.items())))
 PY
   rm -rf $OUT/pmc
+  # HBM traffic of the same kernels: FETCH_SIZE and WRITE_SIZE in passes of their own (MI355X_MICROARCH.md: KB units, read bytes = 2 x FETCH_SIZE on gfx950)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- python3 tools/time_fp32.py 256 > $OUT/pmc_$c.log 2>&1 || exit 1
+  done
+  python3 - <<PY > $OUT/b256_traffic.txt
+import csv, glob, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+    f = glob.glob("$OUT/pmc_%s/**/*counter_collection.csv" % c, recursive=True)[0]
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] == c and 'f32' in r['Kernel_Name']:
+            acc[(r['Kernel_Name'][:64], r['Grid_Size'])][c].append(float(r['Counter_Value']))
+M = 256 * 197
+alg = {'921600': ('qkv', M * 192 * 4 + M * 576 * 4), '1228800': ('fc1', M * 192 * 4 + M * 768 * 4), '393216': ('attention', M * 576 * 4 + M * 192 * 4)}
+for k, c in sorted(acc.items()):
+    fe = sum(c['FETCH_SIZE']) / max(len(c['FETCH_SIZE']), 1); wr = sum(c['WRITE_SIZE']) / max(len(c['WRITE_SIZE']), 1)
+    tr = (2 * fe + wr) * 1024
+    name, a = alg.get(k[1], ('', 0))
+    print('%-66s grid %8s  read %7.1f MB  written %7.1f MB  traffic %7.1f MB%s' % (k[0], k[1], 2 * fe * 1024 / 1e6, wr * 1024 / 1e6, tr / 1e6,
+          ('  (%s: algorithmic %.1f MB, %.2fx)' % (name, a / 1e6, tr / a)) if a else ''))
+PY
+  rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 fi

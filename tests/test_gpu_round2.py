@@ -515,15 +515,15 @@ def test_fp32_reference_precision_mode_meets_north_star_tolerances_end_to_end():
 def test_fp32_mode_two_half_batch_chains_equal_the_single_chain_bit_for_bit():
     """From batch 192 up rovit_vit_forward_f32 runs the batch as two half-batch chains on two streams (csrc/vit_f32.hip).  A token row's
     arithmetic does not depend on which launch computes it, so the features of image i must be the same bits whether it travels in a batch of
-    200 (two chains, image i in either half) or in a batch of 100 (one chain) -- also a race check on the fork / join of the side stream."""
+    201 (two chains, image i in either half) or in batches of 67 / 83 / 51 (one chain, other tile boundaries) -- also a race check on the fork / join of the side stream."""
     sd = ref_cpu.init_rovit_state(seed=5)
     torch.manual_seed(9)
     m = _full_model(sd).eval()
     m.backbone.model.precision = 'fp32'
-    x = torch.randn(200, 3, 224, 224, device=dev())
+    x = torch.randn(201, 3, 224, 224, device=dev())               # odd: the chains get 101 and 100 images, neither a multiple of the row tile
     with torch.no_grad():
         big = m(x)['features']
-        parts = torch.cat([m(x[:100])['features'], m(x[100:])['features']])
+        parts = torch.cat([m(x[:67])['features'], m(x[67:150])['features'], m(x[150:])['features']])
         again = m(x)['features']
     assert torch.isfinite(big).all()
     assert torch.equal(big, parts)

@@ -47,8 +47,11 @@ constexpr int GBM = 128, GBK = 32, GST = GBK + 4;                // GST: LDS row
 //        a fixed order (mean = sum / 192, var = sum of squares / 192 - mean^2, clamped at 0) and applies ((x - mean) rstd) gamma + beta -- the
 //        element-wise order of ln_f32_kernel -- on the staging registers before they go to LDS; gamma / beta and the tile's (mean, rstd) wait in
 //        LDS (2.5 KB).
-// (One-pass variance in fp32: the rows are O(1-100) with |mean| well below the spread, relative error ~1e-7; the fp32-mode parity test holds
-// the whole model to 1e-3 against the CPU oracle and measures 3.6e-6 on the features, as before the fold.)
+// One-pass variance in fp32 is good to ~2e-7 (1 + mean^2 / var): fine for the model's rows (|mean| below the spread), not for a row that is a
+// large offset plus a small signal.  The consumer therefore checks mean^2 > 64 var per row and, for such a row only, recomputes both moments
+// from the row itself in two passes with fp64 accumulators (192 loads by one thread: never taken on the model's own activations, ~2 us per flagged tile when it
+// is; tests: a backbone with its position embedding shifted by +300).  Carrying the sums in fp64 instead was measured: 6.87 -> 6.95 ms per 256
+// images for the 64-bit butterfly.  (Whole model against the CPU oracle: features 3.6e-6, as before the fold.)
 struct F32Ln {
   const float* stats_in;      // LNA
   const float* gamma;
@@ -95,8 +98,17 @@ __global__ __launch_bounds__(256 * WN, WN == 2 ? 2 : 5) void gemm_f32_mfma_kerne
       int m = m0 + tid;
       m = m < M ? m : M - 1;
       const float* sp = ln.stats_in + (size_t)m * 6;
-      const float mean = ((sp[0] + sp[2]) + sp[4]) * (1.f / D);
-      const float var = fmaxf(((sp[1] + sp[3]) + sp[5]) * (1.f / D) - mean * mean, 0.f);
+      float mean = ((sp[0] + sp[2]) + sp[4]) * (1.f / D);
+      float var = fmaxf(((sp[1] + sp[3]) + sp[5]) * (1.f / D) - mean * mean, 0.f);
+      if (mean * mean > 64.f * var) {                                // ill-conditioned for the one-pass form: two passes over the row itself
+        const float* xr = A + (size_t)m * lda;                       // (fp64 accumulators: the path is rare, its accuracy is the point)
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < D; ++k) s1 += (double)xr[k];
+        const double mu = s1 * (1.0 / D);
+        for (int k = 0; k < D; ++k) { const double d = (double)xr[k] - mu; s2 += d * d; }
+        mean = (float)mu;
+        var = (float)(s2 * (1.0 / D));
+      }
       Ms[tid] = make_float2(mean, 1.f / sqrtf(var + ln.eps));
     }
   }

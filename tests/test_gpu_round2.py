@@ -512,6 +512,31 @@ def test_fp32_reference_precision_mode_meets_north_star_tolerances_end_to_end():
     assert m(x[:2].to(dev()))['features'].requires_grad
 
 
+def test_fp32_mode_layernorm_statistics_survive_rows_that_are_a_large_offset_plus_a_small_signal():
+    """norm1 / norm2 of the fp32 forward take their row statistics from one-pass sums written by the producing GEMM (csrc/vit_f32.hip, F32Ln);
+    sum2 / n - mean^2 in fp32 loses the variance when mean^2 >> var, so the consuming GEMM recomputes such rows in two passes.  A position
+    embedding shifted by +300 puts EVERY LayerNorm input of the network in that regime (the residual stream keeps the offset; without the
+    two-pass path the features come out wrong by 4.9).  Truth = the oracle run in fp64; the GPU's fp32 forward must be as close to it as the
+    oracle's own fp32 run is (both carry the rounding of x - mean at |x| ~ 300: measured 2.4e-3 and 2.5e-3)."""
+    sd = dict(ref_cpu.init_rovit_state(seed=3))
+    sd['backbone.model.pos_embed'] = sd['backbone.model.pos_embed'] + 300.0
+    torch.manual_seed(4)
+    x = torch.randn(4, 3, 224, 224)
+    m = _full_model(sd).eval()
+    m.backbone.model.precision = 'fp32'
+    with torch.no_grad():
+        out = m(x.to(dev()))
+        ref32 = ref_cpu.rovit_forward(x, sd, 4)
+        sd64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in sd.items()}
+        ref64 = ref_cpu.rovit_forward(x.double(), sd64, 4)
+    e_gpu = float((out['features'].cpu().double() - ref64['features']).abs().max())
+    e_cpu = float((ref32['features'].double() - ref64['features']).abs().max())
+    print(f'features vs the fp64 oracle with every LayerNorm input at mean 300, spread ~1: GPU fp32 {e_gpu:.2e}, CPU oracle fp32 {e_cpu:.2e}')
+    assert torch.isfinite(out['features']).all()
+    assert e_gpu < max(2.0 * e_cpu, 1e-3), (e_gpu, e_cpu)
+    assert torch.equal(out['cls_logits'].cpu().argmax(1), ref64['cls_logits'].argmax(1))
+
+
 def test_fp32_mode_two_half_batch_chains_equal_the_single_chain_bit_for_bit():
     """From batch 192 up rovit_vit_forward_f32 runs the batch as two half-batch chains on two streams (csrc/vit_f32.hip).  A token row's
     arithmetic does not depend on which launch computes it, so the features of image i must be the same bits whether it travels in a batch of

@@ -462,6 +462,8 @@ extern "C" size_t rovit_vit_f32_workspace_bytes(int batch) {
 // 138 CUs carry two and 118 one), and the other half's launches take what is left free.  Every result is bit-identical to the
 // one-stream order -- a tile's arithmetic does not depend on which launch computes it.  Measured (tools/ab_f32_streams.sh, one box): 8.31 -> 7.8-8.0 ms
 // at batch 256, but 4.97 -> 5.26 at 128 and 3.49 -> 4.44 at 64 (the half-sized grids no longer fill the chip): two chains from batch 192 up.
+// (With the final 128 x 64-tile kernels: 7.09 -> 6.90 at 256; below 192 two chains are within +-1.5 % of one -- 2.60 / 3.27 / 4.10 / 4.68 ms at
+// 64 / 96 / 128 / 160 on one chain, 2.48 / 3.32 / 4.05 / 4.74 on two -- so the threshold stays.)
 extern "C" int rovit_vit_forward_f32(const float* images, const float* const* params, void* workspace, float* features, int batch, int depth,
                                      rovit_stream_t stream) {
   ROVIT_CHECK_ARG(images && params && workspace && features, ROVIT_ERR_NULL, "vit_forward_f32: null pointer");
